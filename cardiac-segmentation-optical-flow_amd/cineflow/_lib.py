@@ -1,0 +1,90 @@
+"""ctypes binding of libcineflow_hip.so (C ABI declared in include/cineflow.h).
+
+The library is mandatory: there is no CPU fallback anywhere in this package.
+``lib()`` raises CineflowLibraryError with build instructions when the shared
+object is missing, and every wrapper in ops.py turns a non-zero return code
+into CineflowError(cf_last_error()).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcineflow_hip.so")
+
+
+class CineflowLibraryError(RuntimeError):
+    pass
+
+
+class CineflowError(RuntimeError):
+    pass
+
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+L = ctypes.c_long
+F = ctypes.c_float
+
+# name -> argtypes, exactly the prototypes of include/cineflow.h (tests/test_abi.py checks both directions)
+SIGNATURES = {
+    "cf_warp_bilinear_2d": [P, P, P, I, I, I, I, P],
+    "cf_vecint_2d": [P, P, P, I, I, I, I, P],
+    "cf_warp_labels_2d": [P, P, P, I, I, I, I, I, P],
+    "cf_memory_input": [P, P, P, P, I, I, I, P],
+    "cf_jacobian_det_2d": [P, P, I, I, I, P],
+    "cf_corr_volume": [P, P, P, I, I, I, I, I, I, P],
+    "cf_corr_pyramid": [P, P, P, I, I, I, I, I, P],
+    "cf_corr_lookup": [P, P, P, I, I, I, I, I, P],
+    "cf_convex_upsample": [P, P, P, I, I, I, I, P],
+    "cf_conv2d": [P, I, P, I, P, L, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, F, P],
+    "cf_conv_transpose2d_k2s2": [P, P, P, P, I, I, I, I, I, I, I, P],
+    "cf_group_norm": [P, P, P, P, P, I, I, I, I, F, I, I, P, P],
+    "cf_layer_norm_cf": [P, P, P, P, I, I, I, F, P],
+    "cf_attention_cf": [P, L, P, L, P, L, P, I, I, I, I, I, P],
+    "cf_gru_reset_mul": [P, P, P, I, I, I, P],
+    "cf_gru_blend": [P, P, P, P, I, I, I, P],
+    "cf_binary": [I, P, P, P, L, L, P],
+    "cf_copy_channels": [P, I, I, P, I, I, I, I, I, I, P],
+    "cf_coords_grid": [P, I, I, I, P],
+    "cf_crop2d": [P, P, I, I, I, I, I, I, I, P],
+    "cf_pad2d": [P, P, I, I, I, I, I, I, I, P],
+    "cf_tta_accumulate": [P, P, I, I, I, I, I, I, F, P],
+    "cf_flip2d": [P, P, I, I, I, I, I, P],
+    "cf_tile_accumulate": [P, P, P, P, I, I, I, I, I, I, I, P],
+    "cf_tile_finalize": [P, P, P, P, I, I, I, P],
+    "cf_argmax_channels": [P, P, I, I, I, P],
+    "cf_profile_enable": [I],
+    "cf_profile_reset": [],
+    "cf_profile_read": [I, P, P, P],
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CineflowLibraryError(
+            "libcineflow_hip.so not found at %s.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C cardiac-segmentation-optical-flow_amd/csrc`).  cineflow has no CPU fallback." % LIB_PATH)
+    try:
+        h = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise CineflowLibraryError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(h, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    h.cf_last_error.restype = ctypes.c_char_p
+    h.cf_last_error.argtypes = []
+    h.cf_version.restype = ctypes.c_int
+    h.cf_version.argtypes = []
+    _lib = h
+    return h
+
+
+def check(rc, name):
+    if rc != 0:
+        raise CineflowError("%s failed (%d): %s" % (name, rc, lib().cf_last_error().decode()))

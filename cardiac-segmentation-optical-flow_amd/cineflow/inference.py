@@ -1,0 +1,224 @@
+"""Sliding-window / TTA inference drivers of the hot path.
+
+Mirrors nnunet/network_architecture/neural_network.py (`SegmentationNetwork`) and the flow-specific overrides of
+nnunet/network_architecture/SegFlowGaussian.py, with the per-tile host<->device round trips of the reference removed:
+tiles, mirrored copies, Gaussian weighting, accumulation, argmax and the label warp all stay in HBM, and every tile
+of every slice goes through the network as ONE batch.  `file:line` citations are relative to /root/reference.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------------ host-side helpers
+def compute_steps_for_sliding_window(patch_size, image_size, step_size):
+    """SegmentationNetwork._compute_steps_for_sliding_window, neural_network.py:267-290 (pure host integer logic)."""
+    assert all(i >= j for i, j in zip(image_size, patch_size)), "image size must be as large or larger than patch_size"
+    assert 0 < step_size <= 1, "step_size must be larger than 0 and smaller or equal to 1"
+    target = [i * step_size for i in patch_size]
+    num_steps = [int(np.ceil((i - k) / j)) + 1 for i, j, k in zip(image_size, target, patch_size)]
+    steps = []
+    for dim in range(len(patch_size)):
+        max_step_value = image_size[dim] - patch_size[dim]
+        actual = max_step_value / (num_steps[dim] - 1) if num_steps[dim] > 1 else 99999999999
+        steps.append([int(np.round(actual * i)) for i in range(num_steps[dim])])
+    return steps
+
+
+def get_gaussian(patch_size, sigma_scale=1.0 / 8):
+    """SegmentationNetwork._get_gaussian, neural_network.py:251-264 (computed once per patch size, on the host)."""
+    from scipy.ndimage import gaussian_filter
+    tmp = np.zeros(patch_size)
+    tmp[tuple(i // 2 for i in patch_size)] = 1
+    g = gaussian_filter(tmp, [i * sigma_scale for i in patch_size], 0, mode="constant", cval=0)
+    g = (g / np.max(g) * 1).astype(np.float32)
+    g[g == 0] = np.min(g[g != 0])
+    return g
+
+
+def pad_nd_image(image, new_shape, mode="constant", kwargs=None, return_slicer=False):
+    """batchgenerators pad_nd_image semantics (call sites neural_network.py:644, SegFlowGaussian.py:3310): pad the
+    trailing len(new_shape) axes to max(new, old), below = diff//2, above = diff//2 + diff%2."""
+    if kwargs is None:
+        kwargs = {"constant_values": 0}
+    old = np.array(image.shape[-len(new_shape):])
+    new = np.array([max(n, o) for n, o in zip(new_shape, old)])
+    diff = new - old
+    below, above = diff // 2, diff // 2 + diff % 2
+    pad_list = [[0, 0]] * (image.ndim - len(new_shape)) + [list(i) for i in zip(below, above)]
+    res = np.pad(image, pad_list, mode, **kwargs) if diff.any() else image
+    if not return_slicer:
+        return res
+    pad_arr = np.array(pad_list)
+    pad_arr[:, 1] = np.array(res.shape) - pad_arr[:, 1]
+    return res, [slice(*i) for i in pad_arr]
+
+
+_gauss_cache = {}
+
+
+def _gaussian_on(device, patch_size):
+    key = (str(device), tuple(patch_size))
+    if key not in _gauss_cache:
+        _gauss_cache[key] = torch.from_numpy(get_gaussian(tuple(patch_size))).to(device)
+    return _gauss_cache[key]
+
+
+# ------------------------------------------------------------------------------------------------ TTA + tiles
+def mirror_and_predict_2d(net, x, mirror_axes=(0, 1), do_mirroring=True, mult=None):
+    """SegmentationNetwork._internal_maybe_mirror_and_pred_2D, neural_network.py:573-621 (upstream 4-argument
+    semantics).  x [B,C,X,Y] on the GPU; returns the TTA-averaged softmax [B,K,X,Y] (times `mult` [X,Y])."""
+    B, _, X, Y = x.shape
+    acc = torch.zeros((B, net.num_classes, X, Y), dtype=torch.float32, device=x.device)
+    n = 2 ** len(mirror_axes) if do_mirroring else 1
+    variants = [(0, 0)]
+    if do_mirroring:
+        if 1 in mirror_axes:
+            variants.append((0, 1))
+        if 0 in mirror_axes:
+            variants.append((1, 0))
+        if 0 in mirror_axes and 1 in mirror_axes:
+            variants.append((1, 1))
+    for fh, fw in variants:
+        xin = x if (fh, fw) == (0, 0) else ops.flip2d(x, fh, fw)
+        ops.tta_accumulate(net(xin), acc, fh, fw, 1.0 / n)
+    if mult is not None:
+        ops.mul(acc, mult, out=acc)
+    return acc
+
+
+def predict_3D_2Dconv_tiled(net, x, patch_size, step_size=0.5, do_mirroring=True, mirror_axes=(0, 1), use_gaussian=True,
+                            pad_border_mode="constant", pad_kwargs=None, max_batch=64, return_device=False):
+    """SegmentationNetwork._internal_predict_3D_2Dconv_tiled (neural_network.py:814-857) over
+    _internal_predict_2D_2Dconv_tiled (:623-769).  x: numpy [C,Z,X,Y] -> (seg [Z,X,Y] uint8, softmax [K,Z,X,Y] fp32).
+    All Z slices and all tiles are batched through the network (the reference loops tile by tile)."""
+    assert x.ndim == 4, "x must be (c, z, x, y)"
+    C, Z = x.shape[0], x.shape[1]
+    patch_size = tuple(patch_size)
+    data, slicer = pad_nd_image(x, patch_size, pad_border_mode, pad_kwargs, True)
+    Xp, Yp = data.shape[2], data.shape[3]
+    steps = compute_steps_for_sliding_window(patch_size, (Xp, Yp), step_size)
+    tiles = [(lx, ly) for lx in steps[0] for ly in steps[1]]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    vol = torch.from_numpy(np.ascontiguousarray(data.transpose(1, 0, 2, 3))).to(dev, dtype=torch.float32)  # [Z,C,Xp,Yp]
+    K = net.num_classes
+    gauss = _gaussian_on(dev, patch_size) if (use_gaussian and len(tiles) > 1) else None
+    agg = torch.zeros((Z, K, Xp, Yp), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((Z, K, Xp, Yp), dtype=torch.float32, device=dev)
+    jobs = [(z, lx, ly) for z in range(Z) for (lx, ly) in tiles]
+    for i0 in range(0, len(jobs), max_batch):
+        chunk = jobs[i0:i0 + max_batch]
+        batch = torch.empty((len(chunk), C) + patch_size, dtype=torch.float32, device=dev)
+        for j, (z, lx, ly) in enumerate(chunk):
+            batch[j] = ops.crop2d(vol[z], lx, ly, patch_size[0], patch_size[1])
+        pred = mirror_and_predict_2d(net, batch, mirror_axes, do_mirroring, gauss)
+        for j, (z, lx, ly) in enumerate(chunk):
+            ops.tile_accumulate(pred[j], gauss, agg[z], cnt[z], lx, ly)
+    segs, probs = [], []
+    for z in range(Z):
+        s, p = ops.tile_finalize(agg[z], cnt[z])
+        segs.append(s)
+        probs.append(p)
+    seg = torch.stack(segs, 0)[:, slicer[2], slicer[3]]
+    prob = torch.stack(probs, 1)[:, :, slicer[2], slicer[3]]
+    if return_device:
+        return seg, prob
+    return seg.cpu().numpy(), prob.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ Processor
+class Processor:
+    """Crop / un-crop arithmetic of nnunet/training/network_training/processor.py:109-138, :178-186, :223-230.
+    The centroid comes from the caller (the reference gets it from a separate 2-class cropping network,
+    processor.py:140-160, which is outside this path -- SURVEY.md row a20)."""
+
+    def __init__(self, crop_size, image_size):
+        self.crop_size, self.image_size = crop_size, image_size
+
+    def adjust_cropping_window(self, centroid):
+        half = self.crop_size // 2
+        x_low = max(0, int(centroid[0]) - half)
+        x_high = min(self.image_size, int(centroid[0]) + half)
+        y_low = max(0, int(centroid[1]) - half)
+        y_high = min(self.image_size, int(centroid[1]) + half)
+        if x_low == 0:
+            x_high = self.crop_size
+        if x_high == self.image_size:
+            x_low = self.image_size - self.crop_size
+        if y_low == 0:
+            y_high = self.crop_size
+        if y_high == self.image_size:
+            y_low = self.image_size - self.crop_size
+        return {"crop_indices": [x_low, x_high, y_low, y_high],
+                "padding_need": [x_low, self.image_size - x_high, y_low, self.image_size - y_high]}
+
+    def crop_and_pad(self, data, mean_centroid):
+        """data [T,1,H,W] (GPU) -> ([T,1,crop,crop], padding_need [left,right,top,bottom])."""
+        p = self.adjust_cropping_window(mean_centroid)
+        c = p["crop_indices"]
+        vol = ops.crop2d(data, c[2], c[0], c[3] - c[2], c[1] - c[0])
+        assert vol.shape[-1] == self.crop_size, vol.shape
+        return vol, p["padding_need"]
+
+    def uncrop_no_registration(self, output, padding_need):
+        """output [...,h,w] -> zero-padded [...,H,W] (F.pad(pad=(left,right,top,bottom)))."""
+        left, right, top, bottom = (int(v) for v in padding_need)
+        h, w = output.shape[-2:]
+        return ops.pad2d(output, top, left, h + top + bottom, w + left + right)
+
+
+# ------------------------------------------------------------------------------------------------ joint seg + flow
+def normalize_intensity_(x):
+    """monai NormalizeIntensity() defaults on a [T,1,h,w] block (SegFlowGaussian.py:3108): whole-block z-score with
+    population std, done by the GroupNorm kernel with one group, eps 0 and no affine."""
+    flat = x.view(1, 1, -1)
+    ops.group_norm(flat, None, None, 1, eps=0.0, out=flat)
+    return x
+
+
+def chunk_orders(T):
+    """SegFlowGaussian.py:3120-3127: frames 1..T-1 split in two chunks (torch.chunk), the second reversed, both
+    starting at frame 0 (ED)."""
+    idx = list(range(1, T))
+    n1 = -(-len(idx) // 2) if len(idx) else 0
+    c1, c2 = idx[:n1], idx[n1:]
+    return [0] + c1, [0] + c2[::-1]
+
+
+def predict_cine_slices(flow_net, seg_net, frames, ed_labels=None, do_mirroring=True, mirror_axes=(0, 1)):
+    """The joint hot path of BASELINE.json config 4 for a batch of slices that are already cropped to the network's
+    patch (SegFlowGaussian._internal_maybe_mirror_and_pred_2D :3120-3230 + _internal_predict_2D_2Dconv_tiled_flow
+    :3427, with the segmentation coming from the 2-D U-Net because SegFlowGaussian.forward has no 'seg' output --
+    SURVEY.md section 0.1).
+
+    frames [T,B,1,H,W] float32 on the GPU (B = slices x patients), z-scored;  ed_labels uint8 [B,H,W] or None
+    (None -> argmax of the ED frame's segmentation is propagated).
+    Returns dict(seg uint8 [T,B,H,W], softmax [T,B,K,H,W], flow [T,B,2,H,W] (frame 0 zero), registered uint8 [T,B,H,W]).
+    """
+    T, B, _, H, W = frames.shape
+    dev = frames.device
+    # segmentation: every frame of every slice is independent -> one batch, flip-TTA on the softmax (:3165-3226)
+    probs = mirror_and_predict_2d(seg_net, frames.reshape(T * B, 1, H, W), mirror_axes, do_mirroring)
+    seg = ops.argmax_channels(probs).view(T, B, H, W)
+    # flow: two half sequences that both start at ED, the second one backwards in time (:3120-3127); flow is not
+    # TTA-averaged (:3162).  Both chunks run as one batch of 2B sequences when they have equal length.
+    flow = torch.zeros((T, B, 2, H, W), dtype=torch.float32, device=dev)
+    o1, o2 = chunk_orders(T)
+    if len(o1) == len(o2) and len(o1) > 1:
+        xin = torch.cat([frames[o1], frames[o2]], dim=1)  # [Tc, 2B, 1, H, W]  (copies only)
+        bf = flow_net(xin)["backward_flow"]
+        for j, t in enumerate(o1[1:]):
+            flow[t] = bf[j, :B]
+        for j, t in enumerate(o2[1:]):
+            flow[t] = bf[j, B:]
+    else:
+        for order in (o1, o2):
+            if len(order) > 1:
+                bf = flow_net(frames[order].contiguous())["backward_flow"]
+                for j, t in enumerate(order[1:]):
+                    flow[t] = bf[j]
+    if ed_labels is None:
+        ed_labels = seg[0].contiguous()
+    registered = ops.warp_labels(flow, ed_labels, flow_net.num_classes if hasattr(flow_net, "num_classes") else 4)
+    return {"seg": seg, "softmax": probs.view(T, B, -1, H, W), "flow": flow, "registered": registered}

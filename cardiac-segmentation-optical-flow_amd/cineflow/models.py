@@ -1,0 +1,450 @@
+"""The flow / segmentation networks of the hot path, on the HIP C ABI.
+
+Same class names, constructor keywords (the subset the YAML configs of the reference actually vary) and
+``state_dict`` keys as the reference; `file:line` citations are relative to /root/reference.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from . import ops
+from .nn import (Module, Conv2d, ConvTranspose2d, GroupNorm, ConvBlocks2DGroupLegacy, Encoder2D, Decoder2D, CrossAttentionLayer,
+                 TransformerFlowEncoderSuccessiveNoEmb, ConvGRUCell, SpatialTransformer, VecInt)
+
+
+# ------------------------------------------------------------------------------------------------ RAFT pieces
+class CorrVolume(Module):
+    """CorrVolume(radius, stride) -- nnunet/lib/raft.py is absent from the reference snapshot; call sites
+    SegFlowGaussian.py:256-261, :1376-1377.  Spec: DESIGN.md "CorrVolume" (parity unpinned)."""
+
+    def __init__(self, radius, stride):
+        super().__init__()
+        self.radius, self.stride = radius, stride
+
+    def forward(self, cur, prev):
+        return ops.corr_volume(cur, prev, self.radius, self.stride)
+
+
+class CorrBlock:
+    """CorrBlock(fmap1, fmap2, radius) -- nnunet/lib/raft_initial.py absent; published RAFT; call sites
+    SegFlowGaussian.py:929, :935."""
+
+    def __init__(self, fmap1, fmap2, num_levels=4, radius=4):
+        self.num_levels, self.radius = num_levels, radius
+        self.pyramid = ops.corr_pyramid(fmap1, fmap2, num_levels)
+
+    def __call__(self, coords):
+        return ops.corr_lookup(self.pyramid, coords, self.num_levels, self.radius)
+
+
+def coords_grid(batch, ht, wd, device):
+    return ops.coords_grid(batch, ht, wd, device)
+
+
+class BasicMotionEncoder(Module):
+    def __init__(self, corr_levels=4, corr_radius=4):
+        super().__init__()
+        cor_planes = corr_levels * (2 * corr_radius + 1) ** 2
+        self.convc1 = Conv2d(cor_planes, 256, 1, padding=0)
+        self.convc2 = Conv2d(256, 192, 3, padding=1)
+        self.convf1 = Conv2d(2, 128, 7, padding=3)
+        self.convf2 = Conv2d(128, 64, 3, padding=1)
+        self.conv = Conv2d(64 + 192, 128 - 2, 3, padding=1)
+
+    def forward(self, flow, corr, out):
+        """writes cat[relu(conv(cat[cor,flo])), flow] into channels [128,256) of `out` ([B,256,h,w] = cat[inp, motion])."""
+        cor = self.convc2(self.convc1(corr, act="relu"), act="relu")
+        flo = self.convf2(self.convf1(flow, act="relu"), act="relu")
+        self.conv(cor, x2=flo, act="relu", out=out, out_coff=128)
+        ops.copy_channels(flow, 0, 2, dst=out, dst_coff=128 + 126)
+        return out
+
+
+class SepConvGRU(Module):
+    """Published RAFT SepConvGRU.  z and r gates of each pass are computed by ONE conv (weights concatenated on
+    Cout at load time, order [r | z]) so the ConvGRU gating kernels are reused."""
+
+    def __init__(self, hidden_dim=128, input_dim=256):
+        super().__init__()
+        c = hidden_dim + input_dim
+        self.hidden_dim = hidden_dim
+        self.convz1 = Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convr1 = Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convq1 = Conv2d(c, hidden_dim, (1, 5), padding=(0, 2))
+        self.convz2 = Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self.convr2 = Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+        self.convq2 = Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
+
+    def _fused(self, cr, cz):
+        if not hasattr(cr, "_wt"):
+            raise RuntimeError("SepConvGRU weights not loaded")
+        return torch.cat([cr._wt, cz._wt], dim=1).contiguous(), torch.cat([cr._p["bias"], cz._p["bias"]]).contiguous()
+
+    def forward(self, h, x):
+        H = self.hidden_dim
+        for (cz, cr, cq) in ((self.convz1, self.convr1, self.convq1), (self.convz2, self.convr2, self.convq2)):
+            key = "_rz_%d" % id(cz)
+            if key not in self.__dict__:
+                self.__dict__[key] = self._fused(cr, cz)
+            wt, b = self.__dict__[key]
+            gates = ops.conv2d(h, wt, b, 2 * H, cz.ks[0], cz.ks[1], 1, cz.pad, x2=x, act="sigmoid")  # [r | z]
+            rh = ops.gru_reset_mul(gates, h)
+            q = cq(rh, x2=x, act="tanh")
+            h = ops.gru_blend(gates, h, q)
+        return h
+
+
+class FlowHead(Module):
+    def __init__(self, input_dim=128, hidden_dim=256):
+        super().__init__()
+        self.conv1 = Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = Conv2d(hidden_dim, 2, 3, padding=1)
+
+    def forward(self, x, res=None):
+        return self.conv2(self.conv1(x, act="relu"), res=res)
+
+
+class BasicUpdateBlock(Module):
+    """Published RAFT BasicUpdateBlock; call site SegFlowGaussian.py:942: net, up_mask, delta = update_block(net, inp, corr, flow)."""
+
+    def __init__(self, hidden_dim=128, corr_levels=4, corr_radius=4):
+        super().__init__()
+        self.encoder = BasicMotionEncoder(corr_levels, corr_radius)
+        self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim)
+        self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
+        self.mask = {0: Conv2d(128, 256, 3, padding=1), 2: Conv2d(256, 64 * 9, 1, padding=0)}
+
+    def forward(self, net, inp_motion, corr, flow):
+        """inp_motion: [B,256,h,w] buffer whose first 128 channels hold `inp`; the motion features are written
+        into the second half (the reference's torch.cat([inp, motion_features]))."""
+        self.encoder(flow, corr, inp_motion)
+        net = self.gru(net, inp_motion)
+        delta = self.flow_head(net)
+        m = self.mask[0](net, act="relu")
+        wt, b = self.mask[2]._wt, self.mask[2]._p["bias"]
+        if "_mask_scaled" not in self.__dict__:
+            self.__dict__["_mask_scaled"] = (0.25 * b).contiguous()  # 0.25 * (W x + b) = alpha * conv + 0.25 b
+        mask = ops.conv2d(m, wt, self.__dict__["_mask_scaled"], 576, 1, 1, alpha=0.25)
+        return net, mask, delta
+
+
+# ------------------------------------------------------------------------------------------------ SegFlowGaussian
+class SegFlowGaussian(Module):
+    """nnunet/network_architecture/SegFlowGaussian.py:70-357, built as nnunet/lib/training_utils.py:1460-1537 maps
+    raft_config.yaml (motion_appearance=True, dim_feedforward=3072) or video.yaml (motion_appearance=False,
+    dim_feedforward=2048).  `forward(x)` with x [T,B,1,H,W] returns {'backward_flow': [T-1,B,2,H,W]} (cumulative
+    ED->t flow) exactly like :1330-1447 / :1813-1912; raft=True runs the RAFT loop of :875-969."""
+
+    def __init__(self, image_size, in_dims=(6, 128, 256), out_encoder_dims=(64, 128, 256), d_model=256, conv_depth=(1, 1, 1),
+                 skip_co_depth=(1, 1, 1), bottleneck_heads=4, nb_layers=1, dim_feedforward=3072, motion_appearance=True,
+                 radius=(4, 4, 4, 4), stride=(4, 2, 1, 1), nb_conv=2, residual=True, extra_block=True, downsample_conv=2, raft=False,
+                 raft_iters=12):
+        super().__init__()
+        in_dims, out_encoder_dims, conv_depth = list(in_dims), list(out_encoder_dims), list(conv_depth)
+        self.num_stages = len(conv_depth)
+        self.d_model, self.image_size = d_model, image_size
+        self.motion_appearance, self.raft, self.raft_iters = motion_appearance, raft, raft_iters
+        self.H = self.W = int(image_size / 2 ** self.num_stages)
+        self.num_classes = 4
+
+        self.integration = VecInt((image_size, image_size), 7)
+        self.motion_estimation = SpatialTransformer((image_size, image_size))
+        in_past = copy.copy(in_dims)
+        in_past[0] = 6
+        enc = dict(d_model=d_model, out_dims=out_encoder_dims, conv_depth=conv_depth, nb_conv=nb_conv, residual=residual,
+                   downsample_conv=downsample_conv)
+        self.memory_encoder = Encoder2D(in_dims=in_past, extra_block=extra_block, **enc)
+        in_q = copy.copy(in_dims)
+        self.skip_co_reduction_list = []
+        if not motion_appearance:
+            in_q[0] = 1
+            self.query_encoder = Encoder2D(in_dims=in_q, extra_block=extra_block, **enc)
+            self.cost_volume_encoder_list, self.cost_volume_computation_list = [], []
+            for idx, (dim, nb) in enumerate(zip(out_encoder_dims, skip_co_depth)):
+                self.cost_volume_computation_list.append(CorrVolume(radius=radius[idx], stride=stride[idx]))
+                self.cost_volume_encoder_list.append(
+                    ConvBlocks2DGroupLegacy((2 * radius[idx] + 1) ** 2, dim, 1, residual=residual))
+                self.skip_co_reduction_list.append(ConvBlocks2DGroupLegacy(2 * dim, dim, nb, residual=residual))
+        else:
+            in_q[0] = 2
+            self.query_encoder = Encoder2D(in_dims=in_q, extra_block=False, motion_appearance=True, **enc)
+            for dim, nb in zip(out_encoder_dims, skip_co_depth):
+                self.skip_co_reduction_list.append(ConvBlocks2DGroupLegacy(2 * dim, dim, nb, residual=residual))
+        dec_in = in_dims[:]
+        dec_in[0] = 4
+        self.flow_decoder = Decoder2D(d_model=d_model, dot_multiplier=2, conv_depth=conv_depth[::-1], in_encoder_dims=dec_in[::-1],
+                                      out_encoder_dims=out_encoder_dims[::-1], num_classes=2, nb_conv=nb_conv, residual=residual)
+        self.gru_cell = ConvGRUCell(input_size=(self.H, self.W), input_dim=d_model, hidden_dim=d_model)
+        self.reduce_transformer = ConvBlocks2DGroupLegacy(d_model * 2, d_model, 1, residual=residual)
+        self.bottleneck1 = CrossAttentionLayer(d_model, bottleneck_heads, nb_layers, dim_feedforward)
+        self.bottleneck2 = CrossAttentionLayer(d_model, bottleneck_heads, nb_layers, dim_feedforward)
+        if raft:
+            self.update_block = BasicUpdateBlock(hidden_dim=d_model // 2)
+
+    def forward(self, x):
+        if self.raft:
+            return self.forward_multi_task_flow_deformable_raft(x)
+        if self.motion_appearance:
+            return self.forward_motion_appearance(x)
+        return self.forward_multi_task_flow_deformable_cost_volume_transformer_cat(x)
+
+    def _step_tail(self, f1, f2, hidden, new_skips, cum, x0, xt):
+        """SegFlowGaussian.py:1410-1435 == :1878-1905."""
+        gru_in = self.reduce_transformer(f1, x2=f2)
+        hidden = self.gru_cell(gru_in, hidden)
+        flow = self.flow_decoder(hidden, new_skips)
+        cum = ops.add(cum, flow)
+        past_motion, past_skips = self.memory_encoder(ops.memory_input(x0, xt, cum))
+        return hidden, cum, past_motion, past_skips
+
+    def forward_motion_appearance(self, x):
+        """SegFlowGaussian.py:1813-1912."""
+        T, B, C, H, W = x.shape
+        dev = x.device
+        cum = torch.zeros((B, 2, H, W), dtype=torch.float32, device=dev)
+        hidden = torch.zeros((B, self.d_model, self.H, self.W), dtype=torch.float32, device=dev)
+        past_motion, past_skips = self.memory_encoder(ops.memory_input(x[0], x[0], cum))
+        pair = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
+        ops.copy_channels(x[0], 0, 1, dst=pair, dst_coff=0)
+        ops.copy_channels(x[0], 0, 1, dst=pair, dst_coff=1)
+        first_app, _, _ = self.query_encoder(pair)
+        prev_app = first_app
+        flows = []
+        for t in range(1, T):
+            pair = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
+            ops.copy_channels(x[t], 0, 1, dst=pair, dst_coff=0)
+            ops.copy_channels(x[t - 1], 0, 1, dst=pair, dst_coff=1)
+            cur_app, _cur_motion, skips = self.query_encoder(pair)
+            new_skips = [self.skip_co_reduction_list[s](skips[s], x2=past_skips[s]) for s in range(self.num_stages)]
+            f1 = self.bottleneck1(query=cur_app, key=prev_app, value=prev_app)
+            f2 = self.bottleneck2(query=cur_app, key=first_app, value=past_motion)
+            hidden, cum, past_motion, past_skips = self._step_tail(f1, f2, hidden, new_skips, cum, x[0], x[t])
+            flows.append(cum)
+            prev_app = cur_app
+        return {"backward_flow": torch.stack(flows, dim=0)}
+
+    def forward_multi_task_flow_deformable_cost_volume_transformer_cat(self, x):
+        """SegFlowGaussian.py:1330-1447 (skip_co_type 'both', correlation_value False, warp False)."""
+        T, B, C, H, W = x.shape
+        dev = x.device
+        cum = torch.zeros((B, 2, H, W), dtype=torch.float32, device=dev)
+        hidden = torch.zeros((B, self.d_model, self.H, self.W), dtype=torch.float32, device=dev)
+        past_motion, past_skips = self.memory_encoder(ops.memory_input(x[0], x[0], cum))
+        first_feat, first_skips = self.query_encoder(x[0])
+        prev_feat, prev_skips = first_feat, first_skips
+        flows = []
+        for t in range(1, T):
+            cur_feat, cur_skips = self.query_encoder(x[t])
+            new_skips = []
+            for s in range(self.num_stages):
+                corr = self.cost_volume_computation_list[s](cur_skips[s], prev_skips[s])
+                corr = self.cost_volume_encoder_list[s](corr)
+                new_skips.append(self.skip_co_reduction_list[s](corr, x2=past_skips[s]))
+            f1 = self.bottleneck1(query=cur_feat, key=prev_feat, value=prev_feat)
+            f2 = self.bottleneck2(query=cur_feat, key=first_feat, value=past_motion)
+            hidden, cum, past_motion, past_skips = self._step_tail(f1, f2, hidden, new_skips, cum, x[0], x[t])
+            flows.append(cum)
+            prev_feat, prev_skips = cur_feat, cur_skips
+        return {"backward_flow": torch.stack(flows, dim=0)}
+
+    def forward_multi_task_flow_deformable_raft(self, x):
+        """SegFlowGaussian.py:875-969; element [0] of the encoders' (feature, skips) tuple is used where the
+        reference splits the tuple itself, and update_block is the published RAFT block."""
+        T, B, C, H, W = x.shape
+        dev = x.device
+        half = self.d_model // 2
+        flow_up = torch.zeros((B, 2, H, W), dtype=torch.float32, device=dev)
+        cnet = self.memory_encoder(ops.memory_input(x[0], x[0], flow_up))[0]
+        net = ops.copy_channels(cnet, 0, half, act="tanh")
+        inp_motion = torch.empty((B, 2 * half, H // 8, W // 8), dtype=torch.float32, device=dev)
+        ops.copy_channels(cnet, half, half, dst=inp_motion, dst_coff=0, act="relu")
+        coords0 = coords_grid(B, H // 8, W // 8, dev)
+        coords1 = coords_grid(B, H // 8, W // 8, dev)
+        f1 = self.query_encoder(x[0])[0]
+        out = []
+        for t in range(1, T):
+            f2 = self.query_encoder(x[t])[0]
+            corr_fn = CorrBlock(f1, f2, radius=4)
+            its = []
+            for _ in range(self.raft_iters):
+                corr = corr_fn(coords1)
+                flow = ops.sub(coords1, coords0)
+                net, up_mask, delta = self.update_block(net, inp_motion, corr, flow)
+                coords1 = ops.add(coords1, delta)
+                flow_up = ops.convex_upsample(ops.sub(coords1, coords0), up_mask)
+                its.append(flow_up)
+            out.append(torch.stack(its, dim=0))
+            cnet = self.memory_encoder(ops.memory_input(x[0], x[t], flow_up))[0]
+            ops.copy_channels(cnet, half, half, dst=inp_motion, dst_coff=0, act="relu")
+        return {"backward_flow": torch.stack(out, dim=1)}
+
+    def warp_linear(self, flow, labels):
+        """SegFlowGaussian.py:3571-3580 (one_hot -> warp -> argmax), fused.  flow [T,B,2,H,W]; labels uint8 [B,H,W]
+        -> uint8 [T,B,H,W]."""
+        return ops.warp_labels(flow, labels, self.num_classes)
+
+
+# ------------------------------------------------------------------------------------------------ successive model
+class OpticalFlowModelSuccessive(Module):
+    """nnunet/network_architecture/Optical_flow_model_successive.py:186-404 with successive.yaml values."""
+
+    def __init__(self, image_size, nb_channels, in_dims=(6, 128, 256), out_encoder_dims=(64, 128, 256), conv_depth=(1, 1, 1),
+                 bottleneck_heads=8, nb_layers=1, nb_conv=2, downsample_conv=1):
+        super().__init__()
+        in_dims, out_encoder_dims, conv_depth = list(in_dims), list(out_encoder_dims), list(conv_depth)
+        self.num_stages = len(conv_depth)
+        self.d_model = out_encoder_dims[-1] * 2
+        self.image_size = image_size
+        self.integration = VecInt((image_size, image_size), 7)
+        in_dims[0] = nb_channels
+        self.encoder = Encoder2D(d_model=self.d_model, out_dims=out_encoder_dims, in_dims=in_dims, conv_depth=conv_depth, nb_conv=nb_conv,
+                                 extra_block=False, residual=False, downsample_conv=downsample_conv)
+        dec_in = in_dims[:]
+        dec_in[0] = 4
+        self.flow_decoder = Decoder2D(d_model=self.d_model, dot_multiplier=2, conv_depth=conv_depth[::-1], in_encoder_dims=dec_in[::-1],
+                                      out_encoder_dims=out_encoder_dims[::-1], num_classes=2, nb_conv=nb_conv, residual=False)
+        self.bottleneck = TransformerFlowEncoderSuccessiveNoEmb(self.d_model, bottleneck_heads, nb_layers)
+        self.skip_co_reduction_list = [ConvBlocks2DGroupLegacy(2 * d, d, 1, nb_conv=nb_conv) for d in out_encoder_dims]
+
+    def forward(self, unlabeled, inference=False):
+        T, B = unlabeled.shape[0], unlabeled.shape[1]
+        # every frame through the shared encoder in ONE batched pass (frames are independent there)
+        x = unlabeled.reshape((T * B,) + tuple(unlabeled.shape[2:]))
+        feat, skips = self.encoder(x)
+        feats = feat.view((T, B) + tuple(feat.shape[1:]))
+        fwd = self.bottleneck(feats)  # [T-1,B,C,h,w]
+        sk_t = [s.view((T, B) + tuple(s.shape[1:])) for s in skips]
+        # adjacent-pair skip reductions and decoding, batched over the T-1 pairs
+        n = (T - 1) * B
+        red = [self.skip_co_reduction_list[s](sk_t[s][:-1].reshape((n,) + tuple(sk_t[s].shape[2:])),
+                                              x2=sk_t[s][1:].reshape((n,) + tuple(sk_t[s].shape[2:])))
+               for s in range(self.num_stages)]
+        flow = self.flow_decoder(fwd.reshape((n,) + tuple(fwd.shape[2:])), red)
+        if inference:
+            flow = self.integration(flow)
+        return {"flow": flow.view((T - 1, B) + tuple(flow.shape[1:]))}
+
+
+class ModelWrap(Module):
+    """Optical_flow_model_successive.py:58-134 (forward_from_ed, no_error=False)."""
+
+    def __init__(self, model1, model2):
+        super().__init__()
+        self.model1, self.model2 = model1, model2
+        self.image_size = model1.image_size
+        self.motion_estimation = SpatialTransformer((self.image_size, self.image_size))
+
+    def forward(self, x, inference=False):
+        out2 = {}
+        out1 = self.model1(x)
+        if len(x) == 2:
+            out2["flow"] = out1["flow"][0]
+            return out1, out2
+        flow1 = out1["flow"]
+        B, _, H, W = x[0].shape
+        cum = flow1[0]
+        cums = [cum]
+        for t in range(1, len(flow1)):
+            reg1 = self.motion_estimation(flow=cum, original=x[t])
+            reg2 = self.motion_estimation(flow=flow1[t], original=x[t + 1])
+            xin = torch.empty((2, B, 6, H, W), dtype=torch.float32, device=x.device)
+            for slot, (fl, a, b, reg) in enumerate(((cum, x[t], x[0], reg1), (flow1[t], x[t + 1], x[t], reg2))):
+                ops.copy_channels(fl, 0, 2, dst=xin[slot], dst_coff=0)
+                ops.copy_channels(a, 0, 1, dst=xin[slot], dst_coff=2)
+                ops.copy_channels(b, 0, 1, dst=xin[slot], dst_coff=3)
+                ops.copy_channels(reg, 0, 1, dst=xin[slot], dst_coff=4)
+                ops.copy_channels(ops.sub(b, reg), 0, 1, dst=xin[slot], dst_coff=5)
+            out = self.model2(xin, inference=inference)
+            cum = ops.add(cum, out["flow"][0])
+            cums.append(cum)
+        out2["flow"] = cum
+        out2["cumulated"] = torch.stack(cums, dim=0)
+        return out1, out2
+
+
+# ------------------------------------------------------------------------------------------------ Generic_UNet (2D)
+class ConvDropoutNormNonlin(Module):
+    """nnunet/network_architecture/generic_UNet.py:26-69: conv3x3 -> InstanceNorm(affine) -> LeakyReLU(0.01)."""
+
+    def __init__(self, cin, cout, stride=1):
+        super().__init__()
+        self.conv = Conv2d(cin, cout, 3, stride=stride, padding=1, bias=True)
+        self.instnorm = GroupNorm(cout, cout)
+
+    def forward(self, x, x2=None):
+        return self.instnorm(self.conv(x, x2=x2), act="lrelu")
+
+
+class StackedConvLayers(Module):
+    """generic_UNet.py:79-144."""
+
+    def __init__(self, cin, cout, num_convs, first_stride=None):
+        super().__init__()
+        self.input_channels, self.output_channels = cin, cout
+        self.blocks = [ConvDropoutNormNonlin(cin, cout, first_stride if first_stride is not None else 1)] + \
+                      [ConvDropoutNormNonlin(cout, cout) for _ in range(num_convs - 1)]
+
+    def forward(self, x, x2=None):
+        for i, b in enumerate(self.blocks):
+            x = b(x, x2=x2) if i == 0 else b(x)
+        return x
+
+
+class Generic_UNet(Module):
+    """generic_UNet.py:167-408 as nnUNetTrainerV2.py:147-169 builds it for 2-D (InstanceNorm affine, LeakyReLU,
+    convolutional pooling / transposed-conv upsampling without bias, 1x1 heads without bias).  forward returns the
+    full-resolution logits (deep supervision off at inference)."""
+
+    MAX_FILTERS_2D = 480
+
+    def __init__(self, input_channels, base_num_features, num_classes, num_pool, num_conv_per_stage=2):
+        super().__init__()
+        self.num_classes = num_classes
+        self.input_channels = input_channels
+        ctx, loc, tu, seg = [], [], [], []
+        out_f, in_f = base_num_features, input_channels
+        for d in range(num_pool):
+            ctx.append(StackedConvLayers(in_f, out_f, num_conv_per_stage, 2 if d != 0 else None))
+            in_f = out_f
+            out_f = min(int(np.round(out_f * 2)), self.MAX_FILTERS_2D)
+        final = out_f
+        ctx.append({0: StackedConvLayers(in_f, out_f, num_conv_per_stage - 1, 2), 1: StackedConvLayers(out_f, final, 1)})
+        skip_ch = [c.output_channels for c in ctx[:-1]]
+        for u in range(num_pool):
+            from_down = final
+            from_skip = skip_ch[-(1 + u)]
+            final = from_skip
+            tu.append(ConvTranspose2d(from_down, from_skip, bias=False))
+            loc.append({0: StackedConvLayers(from_skip * 2, from_skip, num_conv_per_stage - 1), 1: StackedConvLayers(from_skip, final, 1)})
+            seg.append(Conv2d(final, num_classes, 1, bias=False))
+        self.conv_blocks_localization = loc
+        self.conv_blocks_context = ctx
+        self.tu = tu
+        self.seg_outputs = seg
+
+    def _children(self):
+        # lists whose elements are {index: Module} dicts (nn.Sequential inside nn.ModuleList)
+        for k in ("conv_blocks_localization", "conv_blocks_context"):
+            for i, m in enumerate(getattr(self, k)):
+                if isinstance(m, dict):
+                    for j, mm in m.items():
+                        yield "%s.%d.%d" % (k, i, j), mm
+                else:
+                    yield "%s.%d" % (k, i), m
+        for k in ("tu", "seg_outputs"):
+            for i, m in enumerate(getattr(self, k)):
+                yield "%s.%d" % (k, i), m
+
+    def forward(self, x):
+        skips = []
+        for d in range(len(self.conv_blocks_context) - 1):
+            x = self.conv_blocks_context[d](x)
+            skips.append(x)
+        bott = self.conv_blocks_context[-1]
+        x = bott[1](bott[0](x))
+        for u in range(len(self.tu)):
+            up = self.tu[u](x)
+            blk = self.conv_blocks_localization[u]
+            x = blk[1](blk[0](up, x2=skips[-(u + 1)]))
+        return self.seg_outputs[-1](x)

@@ -1,0 +1,477 @@
+"""Host-side mirror of the reference's layer library, executing on the HIP C ABI.
+
+Each class keeps the reference class name, constructor arguments and ``state_dict`` key names (SURVEY.md
+appendix A), so a reference checkpoint (or the seeded fill of cineflow.weights) loads unchanged; `forward`
+issues hand-written HIP kernels only (cineflow.ops).  Tensors are NCHW float32 on the GPU; tokens stay
+channel-first ([B,C,N]) so the reference's permute/contiguous round trips never happen and nn.Linear becomes a
+1x1 convolution on the same implicit-GEMM kernel.  `file:line` citations are relative to /root/reference.
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+class Module:
+    """Minimal module tree: parameters are declared with `_param(name, shape)`, children are attributes that
+    are Modules, lists of Modules, or dicts {index: Module} (for nn.Sequential slots)."""
+
+    def __init__(self):
+        object.__setattr__(self, "_shapes", {})
+        object.__setattr__(self, "_p", {})
+
+    def _param(self, name, shape):
+        self._shapes[name] = tuple(int(s) for s in shape)
+
+    def _children(self):
+        for k, v in self.__dict__.items():
+            if k.startswith("_"):
+                continue
+            if isinstance(v, Module):
+                yield k, v
+            elif isinstance(v, (list, tuple)):
+                for i, m in enumerate(v):
+                    if isinstance(m, Module):
+                        yield "%s.%d" % (k, i), m
+            elif isinstance(v, dict):
+                for i, m in v.items():
+                    if isinstance(m, Module):
+                        yield "%s.%s" % (k, i), m
+
+    def state_shapes(self, prefix=""):
+        out = {prefix + k: v for k, v in self._shapes.items()}
+        for name, child in self._children():
+            out.update(child.state_shapes(prefix + name + "."))
+        return out
+
+    def load_state_dict(self, sd, device, prefix="", strict=True):
+        """sd: mapping name -> CPU/GPU tensor with the reference's key names."""
+        mine = {}
+        for k, shape in self._shapes.items():
+            full = prefix + k
+            if full not in sd:
+                if strict:
+                    raise KeyError("missing parameter %s" % full)
+                continue
+            t = sd[full]
+            if tuple(t.shape) != shape:
+                raise ValueError("shape mismatch for %s: %s vs %s" % (full, tuple(t.shape), shape))
+            mine[k] = t.detach().to(device=device, dtype=torch.float32).contiguous()
+        self._p.update(mine)
+        self._prepare()
+        for name, child in self._children():
+            child.load_state_dict(sd, device, prefix + name + ".", strict)
+        return self
+
+    def _prepare(self):
+        """Hook: derive device-side layouts (pre-transposed weights) after loading."""
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+
+# --------------------------------------------------------------------------------------------- basic layers
+class Conv2d(Module):
+    """nn.Conv2d.  Weights are transposed once to [Cin*KH*KW, Cout] for the implicit-GEMM kernel."""
+
+    def __init__(self, cin, cout, kernel_size=3, stride=1, padding=0, bias=True):
+        super().__init__()
+        ks = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        pd = (padding, padding) if isinstance(padding, int) else tuple(padding)
+        self.cin, self.cout, self.ks, self.stride, self.pad = cin, cout, ks, stride, pd
+        self._param("weight", (cout, cin, ks[0], ks[1]))
+        if bias:
+            self._param("bias", (cout,))
+
+    def _prepare(self):
+        if "weight" in self._p:
+            self._wt = ops.prep_conv_weight(self._p["weight"])
+
+    def forward(self, x, x2=None, act=None, res=None, out=None, out_coff=0):
+        return ops.conv2d(x, self._wt, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad, x2=x2, act=act,
+                          res=res, out=out, out_coff=out_coff)
+
+
+class ConvTranspose2d(Module):
+    """nn.ConvTranspose2d(kernel_size=2, stride=2)."""
+
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self._param("weight", (cin, cout, 2, 2))
+        if bias:
+            self._param("bias", (cout,))
+
+    def forward(self, x, out=None, out_coff=0):
+        return ops.conv_transpose2d_k2s2(x, self._p["weight"], self._p.get("bias"), out=out, out_coff=out_coff)
+
+
+class GroupNorm(Module):
+    """nn.GroupNorm(groups, C) (eps 1e-5) fused with the following activation / residual add.
+    groups == C gives nn.InstanceNorm2d(C, affine=True)."""
+
+    def __init__(self, groups, channels, eps=1e-5):
+        super().__init__()
+        self.groups, self.eps = groups, eps
+        self._param("weight", (channels,))
+        self._param("bias", (channels,))
+
+    def forward(self, x, act=None, res=None, res_mode=None, inplace=True):
+        return ops.group_norm(x, self._p["weight"], self._p["bias"], self.groups, self.eps, act=act, res=res, res_mode=res_mode,
+                              out=x if inplace else None)
+
+
+class LayerNormCF(Module):
+    """nn.LayerNorm(C) applied over the channel axis of channel-first tokens."""
+
+    def __init__(self, channels, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self._param("weight", (channels,))
+        self._param("bias", (channels,))
+
+    def forward(self, x, inplace=True):
+        return ops.layer_norm_cf(x, self._p["weight"], self._p["bias"], self.eps, out=x if inplace else None)
+
+
+# --------------------------------------------------------------------------------------------- lib/utils.py blocks
+class DoubleConv(Module):
+    """nnunet/lib/utils.py:1182-1215: GELU(GN(conv)) twice, residual (optionally 1x1 conv + GN) added after the
+    second GELU.  `x2` is the second half of a channel concatenation (never materialised)."""
+
+    def __init__(self, in_dim, out_dim, residual, stride=1, kernel_size=3):
+        super().__init__()
+        self.conv1 = Conv2d(in_dim, out_dim, kernel_size, stride=stride, padding=1)
+        self.norm1 = GroupNorm(8, out_dim)
+        self.conv2 = Conv2d(out_dim, out_dim, kernel_size, padding=1)
+        self.norm2 = GroupNorm(8, out_dim)
+        self.residual = residual
+        self.has_ds = bool(residual and (in_dim != out_dim or stride != 1))
+        if self.has_ds:
+            self.downsample = {0: Conv2d(in_dim, out_dim, 1, stride=stride), 1: GroupNorm(8, out_dim)}
+
+    def forward(self, x, x2=None):
+        t = self.norm1(self.conv1(x, x2=x2), act="gelu")
+        t = self.conv2(t)
+        if not self.residual:
+            return self.norm2(t, act="gelu")
+        if self.has_ds:
+            r = self.downsample[1](self.downsample[0](x, x2=x2))
+        else:
+            assert x2 is None
+            r = x
+        return self.norm2(t, act="gelu", res=r, res_mode="after_act")
+
+
+class SingleConv(Module):
+    """nnunet/lib/utils.py:1239-1264: residual (bare 1x1 conv) added before the GELU."""
+
+    def __init__(self, in_dim, out_dim, residual, stride=1, kernel_size=3):
+        super().__init__()
+        self.conv1 = Conv2d(in_dim, out_dim, kernel_size, stride=stride, padding=1)
+        self.norm1 = GroupNorm(8, out_dim)
+        self.residual = residual
+        self.has_ds = bool(residual and (in_dim != out_dim or stride != 1))
+        if self.has_ds:
+            self.downsample = Conv2d(in_dim, out_dim, 1, stride=stride)
+
+    def forward(self, x, x2=None):
+        t = self.conv1(x, x2=x2)
+        if not self.residual:
+            return self.norm1(t, act="gelu")
+        r = self.downsample(x, x2=x2) if self.has_ds else x
+        return self.norm1(t, act="gelu", res=r, res_mode="before_act")
+
+
+class ConvBlocks2DGroupLegacy(Module):
+    """nnunet/lib/utils.py:1345-1366 (widths rounded to multiples of 8 at :1349)."""
+
+    def __init__(self, in_dim, out_dim, nb_blocks, stride=1, residual=False, kernel_size=3, nb_conv=2):
+        super().__init__()
+        dims = torch.linspace(in_dim, out_dim, nb_blocks + 1).int()
+        dims[1:] = (torch.round(dims[1:] / 8) * 8).int()
+        fn = DoubleConv if nb_conv == 2 else SingleConv
+        self.blocks = [fn(in_dim=int(dims[i]), out_dim=int(dims[i + 1]), residual=residual, stride=stride) for i in range(nb_blocks)]
+
+    def forward(self, x, x2=None):
+        for i, b in enumerate(self.blocks):
+            x = b(x, x2=x2) if i == 0 else b(x)
+        return x
+
+
+class PatchExpand2DGroup(Module):
+    """nnunet/lib/utils.py:1982-1994: ConvTranspose2d(k2,s2) + GroupNorm(8) + GELU."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.up = {0: ConvTranspose2d(in_dim, out_dim), 1: GroupNorm(8, out_dim)}
+
+    def forward(self, x):
+        return self.up[1](self.up[0](x), act="gelu")
+
+
+class PatchMerging2DGroup(Module):
+    """nnunet/lib/utils.py:2210-2229: conv3x3 stride 2 + GroupNorm(8) + GELU."""
+
+    def __init__(self, in_dim, out_dim):
+        super().__init__()
+        self.reduction = {0: Conv2d(in_dim, out_dim, 3, stride=2, padding=1), 1: GroupNorm(8, out_dim)}
+
+    def forward(self, x):
+        return self.reduction[1](self.reduction[0](x), act="gelu")
+
+
+# --------------------------------------------------------------------------------------------- encoder / decoder
+class Encoder2D(Module):
+    """nnunet/lib/encoder.py:541-660 (Encoder2D) and :689-801 (EncoderMotionAppearance, `motion_appearance=True`:
+    returns (out_conv(x), x, skips))."""
+
+    def __init__(self, d_model, conv_depth, in_dims, out_dims, nb_conv, extra_block, residual, downsample_conv,
+                 motion_appearance=False):
+        super().__init__()
+        self.num_stages = len(conv_depth)
+        self.extra_block, self.motion_appearance = extra_block, motion_appearance
+        self.layers, self.downsample_layers = [], []
+        out_dim = None
+        for i in range(self.num_stages):
+            out_dim = d_model if i == self.num_stages - 1 else in_dims[i + 1]
+            self.layers.append(ConvBlocks2DGroupLegacy(in_dims[i], out_dims[i], conv_depth[i], residual=residual, nb_conv=nb_conv))
+            if downsample_conv == 2:
+                self.downsample_layers.append(
+                    ConvBlocks2DGroupLegacy(out_dims[i], out_dim, 1, residual=residual, nb_conv=nb_conv, stride=2))
+            else:
+                self.downsample_layers.append(PatchMerging2DGroup(out_dims[i], out_dim))
+        if extra_block or motion_appearance:
+            self.out_conv = ConvBlocks2DGroupLegacy(out_dim, out_dim, conv_depth[-1], residual=residual, nb_conv=nb_conv)
+
+    def forward(self, x):
+        skips = []
+        for layer, ds in zip(self.layers, self.downsample_layers):
+            x = layer(x)
+            skips.append(x)
+            x = ds(x)
+        if self.motion_appearance:
+            return self.out_conv(x), x, skips
+        if self.extra_block:
+            x = self.out_conv(x)
+        return x, skips
+
+
+class Decoder2D(Module):
+    """nnunet/lib/decoder_alt.py:807-923: per stage PatchExpand, cat(skip, x) (as a dual-input conv), conv block;
+    final conv3x3 -> num_classes."""
+
+    def __init__(self, d_model, conv_depth, in_encoder_dims, out_encoder_dims, num_classes, dot_multiplier, nb_conv, residual):
+        super().__init__()
+        assert dot_multiplier == 2
+        self.num_stages = len(conv_depth)
+        self.layers, self.upsample_layers = [], []
+        for i in range(self.num_stages):
+            in_dim = d_model if i == 0 else in_encoder_dims[i - 1]
+            self.upsample_layers.append(PatchExpand2DGroup(in_dim, out_encoder_dims[i]))
+            self.layers.append(ConvBlocks2DGroupLegacy(out_encoder_dims[i] * 2, out_encoder_dims[i], conv_depth[i], nb_conv=nb_conv,
+                                                       residual=residual))
+        self.final_conv = Conv2d(out_encoder_dims[-1], num_classes, 3, padding=1)
+
+    def forward(self, x, skips):
+        for layer, up, skip in zip(self.layers, self.upsample_layers, reversed(skips)):
+            x = layer(skip, x2=up(x))
+        return self.final_conv(x)
+
+
+# --------------------------------------------------------------------------------------------- transformers
+_pos_cache = {}
+
+
+def position_embedding_sine_2d(H, W, C, device, temperature=10000.0, scale=2 * math.pi):
+    """PositionEmbeddingSine2d(num_pos_feats=C/2, normalize=True), nnunet/lib/position_embedding.py:88-107.
+    Input independent: computed once per (H, W, C) on the host and cached on the device as [1, C, H*W]."""
+    key = (H, W, C, str(device))
+    if key not in _pos_cache:
+        npf = C // 2
+        y_embed = torch.arange(1, H + 1, dtype=torch.float32)[:, None].expand(H, W)
+        x_embed = torch.arange(1, W + 1, dtype=torch.float32)[None, :].expand(H, W)
+        eps = 1e-6
+        y_embed = y_embed / (y_embed[-1:, :] + eps) * scale
+        x_embed = x_embed / (x_embed[:, -1:] + eps) * scale
+        dim_t = torch.arange(npf, dtype=torch.float32)
+        dim_t = temperature ** (2 * (dim_t // 2) / npf)
+        pos_x = x_embed[:, :, None] / dim_t
+        pos_y = y_embed[:, :, None] / dim_t
+        pos_x = torch.stack((pos_x[:, :, 0::2].sin(), pos_x[:, :, 1::2].cos()), dim=3).flatten(2)
+        pos_y = torch.stack((pos_y[:, :, 0::2].sin(), pos_y[:, :, 1::2].cos()), dim=3).flatten(2)
+        pos = torch.cat((pos_y, pos_x), dim=2).permute(2, 0, 1).reshape(1, C, H * W).contiguous()
+        _pos_cache[key] = pos.to(device)
+    return _pos_cache[key]
+
+
+class MultiheadAttention(Module):
+    """nn.MultiheadAttention(d_model, nhead, batch_first=True) parameters; projections run as 1x1 convs on
+    channel-first tokens, the core as cf_attention_cf."""
+
+    def __init__(self, d_model, nhead):
+        super().__init__()
+        self.C, self.nhead = d_model, nhead
+        self._param("in_proj_weight", (3 * d_model, d_model))
+        self._param("in_proj_bias", (3 * d_model,))
+        self.out_proj = _Linear(d_model, d_model)
+
+    def _prepare(self):
+        if "in_proj_weight" in self._p:
+            C = self.C
+            w, b = self._p["in_proj_weight"], self._p["in_proj_bias"]
+            self._wq, self._wk, self._wv = (w[i * C:(i + 1) * C].t().contiguous() for i in range(3))
+            self._wqk = w[:2 * C].t().contiguous()
+            self._bq, self._bk, self._bv = (b[i * C:(i + 1) * C].contiguous() for i in range(3))
+            self._bqk = b[:2 * C].contiguous()
+
+    def forward(self, q_in, k_in, v_in, residual, same_qk=False):
+        """q_in [B,C,Nq,1], k_in/v_in [B,C,Nk,1]; returns residual + out_proj(attention)."""
+        C = self.C
+        B, _, Nq, _ = q_in.shape
+        if same_qk:
+            qk = ops.conv2d(q_in, self._wqk, self._bqk, 2 * C, 1, 1)
+            q, k = qk.view(B, 2 * C, Nq).narrow(1, 0, C), qk.view(B, 2 * C, Nq).narrow(1, C, C)
+        else:
+            q = ops.conv2d(q_in, self._wq, self._bq, C, 1, 1).view(B, C, Nq)
+            k = ops.conv2d(k_in, self._wk, self._bk, C, 1, 1).view(B, C, -1)
+        v = ops.conv2d(v_in, self._wv, self._bv, C, 1, 1).view(B, C, -1)
+        att = ops.attention_cf(q, k, v, self.nhead).view(B, C, Nq, 1)
+        return self.out_proj(att, res=residual)
+
+
+class _Linear(Module):
+    """nn.Linear on channel-first tokens [B,Cin,N,1] == 1x1 conv."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self._param("weight", (cout, cin))
+        self._param("bias", (cout,))
+
+    def _prepare(self):
+        if "weight" in self._p:
+            self._wt = self._p["weight"].t().contiguous()
+
+    def forward(self, x, act=None, res=None):
+        return ops.conv2d(x, self._wt, self._p["bias"], self.cout, 1, 1, act=act, res=res)
+
+
+class TransformerFlowLayer(Module):
+    """nnunet/lib/vit_transformer.py:1228-1270, post-norm: self-MHA(q=k=x+pos, v=x) -> LN -> cross-MHA(q=x+pos,
+    k=key+pos, v=value) -> LN -> FFN(GELU) -> LN.  Residual adds are fused in the projection epilogues."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead)
+        self.cross_attn = MultiheadAttention(d_model, nhead)
+        self.linear1 = _Linear(d_model, dim_feedforward)
+        self.linear2 = _Linear(dim_feedforward, d_model)
+        self.norm1, self.norm2, self.norm3 = LayerNormCF(d_model), LayerNormCF(d_model), LayerNormCF(d_model)
+
+    def forward(self, query, key_pos_added, value, pos):
+        """query, value [B,C,N,1]; key_pos_added = key + pos (precomputed by the caller); pos [1,C,N] broadcast."""
+        B, C, N, _ = query.shape
+        qp = ops.add(query, pos)
+        x = self.self_attn(qp, qp, query, residual=query, same_qk=True)
+        x = self.norm1(x.view(B, C, N)).view(B, C, N, 1)
+        qp = ops.add(x, pos)
+        x = self.cross_attn(qp, key_pos_added, value, residual=x)
+        x = self.norm2(x.view(B, C, N)).view(B, C, N, 1)
+        t = self.linear1(x, act="gelu")
+        x = self.linear2(t, res=x)
+        return self.norm3(x.view(B, C, N)).view(B, C, N, 1)
+
+
+class CrossAttentionLayer(Module):
+    """nnunet/lib/vit_transformer.py:5240-5287 ([B,C,H,W] in/out)."""
+
+    def __init__(self, dim, nhead, num_layers, dim_feedforward):
+        super().__init__()
+        self.dim = dim
+        self.bilateral_attention_layers = [TransformerFlowLayer(dim, nhead, dim_feedforward) for _ in range(num_layers)]
+
+    def forward(self, query, key, value):
+        B, C, H, W = query.shape
+        pos = position_embedding_sine_2d(H, W, C, query.device)
+        q = query.view(B, C, H * W, 1)
+        kp = ops.add(key.view(B, C, H * W, 1), pos)
+        v = value.view(B, C, H * W, 1)
+        for layer in self.bilateral_attention_layers:
+            q = layer(q, kp, v, pos)
+        return q.view(B, C, H, W)
+
+
+class TransformerFlowEncoderSuccessiveNoEmb(Module):
+    """nnunet/lib/vit_transformer.py:3596-3641: the layer applied symmetrically to (forward, backward) adjacent
+    frame pairs stacked on the batch axis.  Input [T,B,C,H,W] -> [T-1,B,C,H,W]."""
+
+    def __init__(self, dim, nhead, num_layers):
+        super().__init__()
+        self.bilateral_attention_layers = [TransformerFlowLayer(dim, nhead) for _ in range(num_layers)]
+
+    def forward(self, u):
+        T, B, C, H, W = u.shape
+        N = H * W
+        pos = position_embedding_sine_2d(H, W, C, u.device)
+        flat = u.reshape(T * B, C, N, 1)
+        bwd = flat[:(T - 1) * B]
+        fwd = flat[B:]
+        for layer in self.bilateral_attention_layers:
+            c0 = torch.cat([fwd, bwd], dim=0)  # pure copies (batch-axis concatenation)
+            c1 = torch.cat([bwd, fwd], dim=0)
+            c0 = layer(c0, ops.add(c1, pos), c1, pos)
+            fwd, bwd = c0[:(T - 1) * B], c0[(T - 1) * B:]
+        return fwd.reshape(T - 1, B, C, H, W)
+
+
+# --------------------------------------------------------------------------------------------- ConvGRU, warp
+class ConvGRUCell(Module):
+    """nnunet/network_architecture/convGRU.py:7-69.  cat([x,h]) and cat([x,r*h]) are dual-input convs; sigmoid and
+    tanh are conv epilogues."""
+
+    def __init__(self, input_size, input_dim, hidden_dim, kernel_size=(3, 3), bias=True):
+        super().__init__()
+        self.height, self.width = input_size
+        self.hidden_dim = hidden_dim
+        pad = (kernel_size[0] // 2, kernel_size[1] // 2)
+        self.conv_gates = Conv2d(input_dim + hidden_dim, 2 * hidden_dim, kernel_size, padding=pad, bias=bias)
+        self.conv_can = Conv2d(input_dim + hidden_dim, hidden_dim, kernel_size, padding=pad, bias=bias)
+
+    def forward(self, x, h):
+        gates = self.conv_gates(x, x2=h, act="sigmoid")
+        rh = ops.gru_reset_mul(gates, h)
+        cand = self.conv_can(x, x2=rh, act="tanh")
+        return ops.gru_blend(gates, h, cand)
+
+
+class SpatialTransformer(Module):
+    """nnunet/network_architecture/integration.py:37-79 (2-D).  Keeps the reference's persistent `grid` buffer
+    key so checkpoints load, but the kernel never reads it."""
+
+    def __init__(self, size, mode="bilinear"):
+        super().__init__()
+        self.size = tuple(size)
+        self.mode = mode
+
+    def state_shapes(self, prefix=""):
+        return {prefix + "grid": (1, len(self.size)) + self.size}
+
+    def load_state_dict(self, sd, device, prefix="", strict=True):
+        return self  # the identity grid is implicit in the kernel
+
+    def forward(self, flow, original, mode="bilinear"):
+        return ops.warp_bilinear(flow, original)
+
+
+class VecInt(Module):
+    """integration.py:82-99."""
+
+    def __init__(self, inshape, nsteps):
+        super().__init__()
+        self.nsteps = nsteps
+        self.transformer = SpatialTransformer(inshape)
+
+    def forward(self, vec):
+        return ops.vecint(vec, self.nsteps)

@@ -1,0 +1,322 @@
+"""Thin tensor-level wrappers over the C ABI (include/cineflow.h).
+
+PyTorch is used for device memory (torch.empty on the caching allocator) and the current HIP stream only; every
+number is produced by a hand-written HIP kernel in libcineflow_hip.so.  Inputs must be CUDA(=HIP) tensors; nothing
+here runs on the CPU and nothing falls back to torch operators.
+"""
+import torch
+
+from ._lib import lib, check
+
+ACT = {None: 0, "none": 0, "gelu": 1, "relu": 2, "lrelu": 3, "tanh": 4, "sigmoid": 5}
+RES = {None: 0, "none": 0, "before_act": 1, "after_act": 2}
+OP = {"add": 0, "sub": 1, "mul": 2}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a CUDA/HIP tensor (cineflow has no CPU path)" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t.data_ptr()
+
+
+def _u8(t, name="tensor"):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.uint8 or not t.is_contiguous():
+        raise TypeError("%s must be a contiguous CUDA uint8 tensor" % name)
+    return t.data_ptr()
+
+
+def _opt(t, name="tensor"):
+    return None if t is None else _f32(t, name)
+
+
+# ------------------------------------------------------------------------------------------------ warp family
+def warp_bilinear(flow, src):
+    B, C, H, W = src.shape
+    assert flow.shape == (B, 2, H, W), (flow.shape, src.shape)
+    out = torch.empty_like(src)
+    check(lib().cf_warp_bilinear_2d(_f32(flow), _f32(src), _f32(out), B, C, H, W, _stream()), "cf_warp_bilinear_2d")
+    return out
+
+
+def vecint(vec, nsteps=7):
+    B, two, H, W = vec.shape
+    assert two == 2
+    out = torch.empty_like(vec)
+    tmp = torch.empty_like(vec)
+    check(lib().cf_vecint_2d(_f32(vec), _f32(out), _f32(tmp), B, H, W, nsteps, _stream()), "cf_vecint_2d")
+    return out
+
+
+def warp_labels(flow, labels, num_classes=4):
+    """flow [T,B,2,H,W] float32; labels uint8 [B,H,W] -> uint8 [T,B,H,W]."""
+    T, B, two, H, W = flow.shape
+    assert two == 2 and labels.shape == (B, H, W)
+    out = torch.empty((T, B, H, W), dtype=torch.uint8, device=flow.device)
+    check(lib().cf_warp_labels_2d(_f32(flow), _u8(labels), _u8(out), T, B, num_classes, H, W, _stream()), "cf_warp_labels_2d")
+    return out
+
+
+def memory_input(x0, xt, cum):
+    B, one, H, W = x0.shape
+    assert one == 1 and xt.shape == x0.shape and cum.shape == (B, 2, H, W)
+    out = torch.empty((B, 6, H, W), dtype=torch.float32, device=x0.device)
+    check(lib().cf_memory_input(_f32(x0), _f32(xt), _f32(cum), _f32(out), B, H, W, _stream()), "cf_memory_input")
+    return out
+
+
+def jacobian_det(disp):
+    """disp [B,2,H,W] float32 -> float64 [B,H,W]."""
+    B, two, H, W = disp.shape
+    assert two == 2
+    out = torch.empty((B, H, W), dtype=torch.float64, device=disp.device)
+    check(lib().cf_jacobian_det_2d(_f32(disp), out.data_ptr(), B, H, W, _stream()), "cf_jacobian_det_2d")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ correlation
+def corr_volume(cur, prev, radius=4, stride=1):
+    B, C, H, W = cur.shape
+    assert prev.shape == cur.shape
+    out = torch.empty((B, (2 * radius + 1) ** 2, H, W), dtype=torch.float32, device=cur.device)
+    check(lib().cf_corr_volume(_f32(cur), _f32(prev), _f32(out), B, C, H, W, radius, stride, _stream()), "cf_corr_volume")
+    return out
+
+
+def pyramid_numel(B, H, W, levels):
+    N = H * W
+    return sum(B * N * (H >> l) * (W >> l) for l in range(levels))
+
+
+def corr_pyramid(f1, f2, levels=4):
+    B, C, H, W = f1.shape
+    assert f2.shape == f1.shape
+    pyr = torch.empty(pyramid_numel(B, H, W, levels), dtype=torch.float32, device=f1.device)
+    check(lib().cf_corr_pyramid(_f32(f1), _f32(f2), _f32(pyr), B, C, H, W, levels, _stream()), "cf_corr_pyramid")
+    return pyr
+
+
+def corr_lookup(pyr, coords, levels=4, radius=4):
+    B, two, H, W = coords.shape
+    assert two == 2 and pyr.numel() == pyramid_numel(B, H, W, levels)
+    out = torch.empty((B, levels * (2 * radius + 1) ** 2, H, W), dtype=torch.float32, device=coords.device)
+    check(lib().cf_corr_lookup(_f32(pyr), _f32(coords), _f32(out), B, H, W, levels, radius, _stream()), "cf_corr_lookup")
+    return out
+
+
+def convex_upsample(flow, mask):
+    B, C, h, w = flow.shape
+    assert mask.shape == (B, 576, h, w)
+    out = torch.empty((B, C, 8 * h, 8 * w), dtype=torch.float32, device=flow.device)
+    check(lib().cf_convex_upsample(_f32(flow), _f32(mask), _f32(out), B, C, h, w, _stream()), "cf_convex_upsample")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ conv / norm / attention
+def prep_conv_weight(w):
+    """torch conv weight [Cout,Cin,KH,KW] -> Wt [Cin*KH*KW, Cout] (done once at model load)."""
+    cout = w.shape[0]
+    return w.reshape(cout, -1).t().contiguous()
+
+
+def conv2d(x1, wt, bias, cout, kh, kw, stride=1, pad=(0, 0), x2=None, act=None, res=None, out=None, out_coff=0, alpha=1.0,
+           w_bstride=0):
+    """act(alpha*conv(cat[x1,x2]) + bias) + res, written into channels [out_coff, out_coff+cout) of `out`."""
+    B, C1, H, W = x1.shape
+    C2 = 0 if x2 is None else x2.shape[1]
+    if x2 is not None:
+        assert x2.shape[0] == B and x2.shape[2:] == x1.shape[2:]
+    assert wt.shape == ((C1 + C2) * kh * kw, cout) or w_bstride, (wt.shape, C1, C2, kh, kw, cout)
+    Ho = (H + 2 * pad[0] - kh) // stride + 1
+    Wo = (W + 2 * pad[1] - kw) // stride + 1
+    if out is None:
+        out = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x1.device)
+    assert out.shape[0] == B and out.shape[2] == Ho and out.shape[3] == Wo
+    if res is not None:
+        assert res.shape == (B, cout, Ho, Wo)
+    check(lib().cf_conv2d(_f32(x1), C1, _opt(x2), C2, _f32(wt), w_bstride, _opt(bias), _opt(res), _f32(out), out.shape[1], out_coff,
+                          B, H, W, cout, kh, kw, stride, pad[0], pad[1], ACT[act], float(alpha), _stream()), "cf_conv2d")
+    return out
+
+
+def conv_transpose2d_k2s2(x, w, bias, out=None, out_coff=0):
+    """w in torch layout [Cin,Cout,2,2]."""
+    B, Cin, H, W = x.shape
+    assert w.shape[0] == Cin and w.shape[2:] == (2, 2)
+    cout = w.shape[1]
+    if out is None:
+        out = torch.empty((B, cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    check(lib().cf_conv_transpose2d_k2s2(_f32(x), _f32(w), _opt(bias), _f32(out), out.shape[1], out_coff, B, Cin, H, W, cout,
+                                         _stream()), "cf_conv_transpose2d_k2s2")
+    return out
+
+
+_ws_cache = {}
+
+
+def _stats_ws(n, device):
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 4096), dtype=torch.float64, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def group_norm(x, gamma, beta, groups, eps=1e-5, act=None, res=None, res_mode=None, out=None):
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    if out is None:
+        out = torch.empty_like(x)
+    ws = _stats_ws(2 * B * groups, x.device)
+    check(lib().cf_group_norm(_f32(x), _opt(gamma), _opt(beta), _opt(res), _f32(out), B, C, HW, groups, float(eps), ACT[act],
+                              RES[res_mode if res is not None else None], ws.data_ptr(), _stream()), "cf_group_norm")
+    return out
+
+
+def layer_norm_cf(x, gamma, beta, eps=1e-5, out=None):
+    B, C, N = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().cf_layer_norm_cf(_f32(x), _f32(gamma), _f32(beta), _f32(out), B, C, N, float(eps), _stream()), "cf_layer_norm_cf")
+    return out
+
+
+def _cf_slice(t, name):
+    """[B,C,N] tensor that is either contiguous or a channel slice (narrow on dim 1) of a contiguous buffer."""
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 3:
+        raise TypeError("%s must be a 3-D CUDA float32 tensor" % name)
+    B, C, N = t.shape
+    if t.stride(2) != 1 or t.stride(1) != N:
+        raise ValueError("%s must be contiguous in its last two dims" % name)
+    return t.data_ptr(), (t.stride(0) if B > 1 else max(t.stride(0), C * N))
+
+
+def attention_cf(q, k, v, heads):
+    """q [B,C,Nq], k/v [B,C,Nk] channel-first; each may be a channel slice of a fused projection buffer."""
+    B, C, Nq = q.shape
+    Nk = k.shape[2]
+    assert k.shape == (B, C, Nk) and v.shape == (B, C, Nk) and C % heads == 0
+    qp, qbs = _cf_slice(q, "q")
+    kp, kbs = _cf_slice(k, "k")
+    vp, vbs = _cf_slice(v, "v")
+    out = torch.empty((B, C, Nq), dtype=torch.float32, device=q.device)
+    check(lib().cf_attention_cf(qp, qbs, kp, kbs, vp, vbs, _f32(out), B, heads, C // heads, Nq, Nk, _stream()), "cf_attention_cf")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ plumbing kernels
+def gru_reset_mul(gates, h):
+    B, C = h.shape[0], h.shape[1]
+    HW = h.numel() // (B * C)
+    out = torch.empty_like(h)
+    check(lib().cf_gru_reset_mul(_f32(gates), _f32(h), _f32(out), B, C, HW, _stream()), "cf_gru_reset_mul")
+    return out
+
+
+def gru_blend(gates, h, cand):
+    B, C = h.shape[0], h.shape[1]
+    HW = h.numel() // (B * C)
+    out = torch.empty_like(h)
+    check(lib().cf_gru_blend(_f32(gates), _f32(h), _f32(cand), _f32(out), B, C, HW, _stream()), "cf_gru_blend")
+    return out
+
+
+def binary(op, a, b, out=None):
+    """a op b with b broadcast over the leading dims of a (b.numel() divides a.numel())."""
+    n, period = a.numel(), b.numel()
+    assert n % period == 0
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().cf_binary(OP[op], _f32(a), _f32(b), _f32(out), n, period, _stream()), "cf_binary")
+    return out
+
+
+def add(a, b, out=None):
+    return binary("add", a, b, out)
+
+
+def sub(a, b, out=None):
+    return binary("sub", a, b, out)
+
+
+def mul(a, b, out=None):
+    return binary("mul", a, b, out)
+
+
+def copy_channels(src, src_coff, C, dst=None, dst_coff=0, act=None):
+    B, sct = src.shape[0], src.shape[1]
+    HW = src.numel() // (B * sct)
+    if dst is None:
+        dst = torch.empty((B, C) + tuple(src.shape[2:]), dtype=torch.float32, device=src.device)
+    check(lib().cf_copy_channels(_f32(src), sct, src_coff, _f32(dst), dst.shape[1], dst_coff, B, C, HW, ACT[act], _stream()),
+          "cf_copy_channels")
+    return dst
+
+
+def coords_grid(B, H, W, device):
+    out = torch.empty((B, 2, H, W), dtype=torch.float32, device=device)
+    check(lib().cf_coords_grid(_f32(out), B, H, W, _stream()), "cf_coords_grid")
+    return out
+
+
+def crop2d(src, y0, x0, h, w):
+    lead, (H, W) = src.shape[:-2], src.shape[-2:]
+    N = src.numel() // (H * W)
+    dst = torch.empty(tuple(lead) + (h, w), dtype=torch.float32, device=src.device)
+    check(lib().cf_crop2d(_f32(src), _f32(dst), N, H, W, y0, x0, h, w, _stream()), "cf_crop2d")
+    return dst
+
+
+def pad2d(src, y0, x0, H, W):
+    lead, (h, w) = src.shape[:-2], src.shape[-2:]
+    N = src.numel() // (h * w)
+    dst = torch.empty(tuple(lead) + (H, W), dtype=torch.float32, device=src.device)
+    check(lib().cf_pad2d(_f32(src), _f32(dst), N, h, w, y0, x0, H, W, _stream()), "cf_pad2d")
+    return dst
+
+
+def tta_accumulate(logits, acc, flip_h, flip_w, weight):
+    B, K, H, W = logits.shape
+    assert acc.shape == logits.shape
+    check(lib().cf_tta_accumulate(_f32(logits), _f32(acc), B, K, H, W, int(flip_h), int(flip_w), float(weight), _stream()),
+          "cf_tta_accumulate")
+    return acc
+
+
+def flip2d(src, flip_h, flip_w):
+    H, W = src.shape[-2:]
+    N = src.numel() // (H * W)
+    dst = torch.empty_like(src)
+    check(lib().cf_flip2d(_f32(src), _f32(dst), N, H, W, int(flip_h), int(flip_w), _stream()), "cf_flip2d")
+    return dst
+
+
+def tile_accumulate(pred, gauss, agg, cnt, lx, ly):
+    K, ph, pw = pred.shape
+    _, X, Y = agg.shape
+    check(lib().cf_tile_accumulate(_f32(pred), _opt(gauss), _f32(agg), _f32(cnt), K, X, Y, lx, ly, ph, pw, _stream()),
+          "cf_tile_accumulate")
+
+
+def tile_finalize(agg, cnt):
+    K, X, Y = agg.shape
+    probs = torch.empty_like(agg)
+    seg = torch.empty((X, Y), dtype=torch.uint8, device=agg.device)
+    check(lib().cf_tile_finalize(_f32(agg), _f32(cnt), _f32(probs), _u8(seg), K, X, Y, _stream()), "cf_tile_finalize")
+    return seg, probs
+
+
+def argmax_channels(x):
+    B, K = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * K)
+    out = torch.empty((B,) + tuple(x.shape[2:]), dtype=torch.uint8, device=x.device)
+    check(lib().cf_argmax_channels(_f32(x), _u8(out), B, K, HW, _stream()), "cf_argmax_channels")
+    return out

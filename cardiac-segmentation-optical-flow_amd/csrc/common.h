@@ -1,0 +1,123 @@
+// Shared host/device helpers for libcineflow_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/cineflow.h"
+
+namespace cf {
+
+void set_error(const std::string& s);
+
+#define CF_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            char _b[512];                                       \
+            snprintf(_b, sizeof(_b), __VA_ARGS__);              \
+            cf::set_error(std::string(__func__) + ": " + _b);   \
+            return CF_ERR_ARG;                                  \
+        }                                                       \
+    } while (0)
+
+#define CF_CHECK_LAUNCH()                                                                  \
+    do {                                                                                   \
+        hipError_t _e = hipGetLastError();                                                 \
+        if (_e != hipSuccess) {                                                            \
+            cf::set_error(std::string(__func__) + ": launch failed: " + hipGetErrorString(_e)); \
+            return CF_ERR_LAUNCH;                                                          \
+        }                                                                                  \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// grid size for a flat memory-bound kernel: enough blocks to fill 256 CUs, grid-stride the rest
+static inline int flat_grid(long n, int block, int per_thread = 1) {
+    long blocks = (n + (long)block * per_thread - 1) / ((long)block * per_thread);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256L * 16) blocks = 256L * 16;
+    return (int)blocks;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+        case CF_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case CF_ACT_RELU: return v > 0.f ? v : 0.f;
+        case CF_ACT_LRELU: return v > 0.f ? v : 0.01f * v;
+        case CF_ACT_TANH: return tanhf(v);
+        case CF_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+        default: return v;
+    }
+}
+
+// Sampling coordinate of SpatialTransformer.forward (integration.py:61-79) followed by
+// grid_sample's align_corners=True un-normalisation, with the reference's fp32 rounding path:
+//   g = 2 * ((i + f) / (S - 1) - 0.5);  pos = ((g + 1) / 2) * (S - 1)
+// Contraction into FMAs is prevented so that every intermediate rounds as in PyTorch.
+__device__ __forceinline__ float st_coord(float idx, float f, float size_m1) {
+    float loc = __fadd_rn(idx, f);
+    float g = __fmul_rn(2.0f, __fsub_rn(__fdiv_rn(loc, size_m1), 0.5f));
+    return __fmul_rn(__fdiv_rn(__fadd_rn(g, 1.0f), 2.0f), size_m1);
+}
+
+// Bilinear tap set with zero padding (grid_sample padding_mode='zeros').
+struct Taps {
+    int y0, x0;
+    float w00, w01, w10, w11;  // (y0,x0) (y0,x0+1) (y0+1,x0) (y0+1,x0+1)
+    bool v00, v01, v10, v11;
+};
+
+__device__ __forceinline__ Taps make_taps(float y, float x, int H, int W) {
+    Taps t;
+    float yf = floorf(y), xf = floorf(x);
+    float wy = __fsub_rn(y, yf), wx = __fsub_rn(x, xf);
+    float ey = __fsub_rn(1.0f, wy), ex = __fsub_rn(1.0f, wx);
+    // guard the float->int conversion against huge / NaN coordinates
+    yf = fminf(fmaxf(yf, -2.0f), (float)H + 1.0f);
+    xf = fminf(fmaxf(xf, -2.0f), (float)W + 1.0f);
+    t.y0 = (int)yf;
+    t.x0 = (int)xf;
+    t.w00 = __fmul_rn(ex, ey);
+    t.w01 = __fmul_rn(wx, ey);
+    t.w10 = __fmul_rn(ex, wy);
+    t.w11 = __fmul_rn(wx, wy);
+    bool y0v = t.y0 >= 0 && t.y0 < H, y1v = t.y0 + 1 >= 0 && t.y0 + 1 < H;
+    bool x0v = t.x0 >= 0 && t.x0 < W, x1v = t.x0 + 1 >= 0 && t.x0 + 1 < W;
+    bool fin = (y == y) && (x == x) && fabsf(y) < 1e9f && fabsf(x) < 1e9f;
+    t.v00 = fin && y0v && x0v;
+    t.v01 = fin && y0v && x1v;
+    t.v10 = fin && y1v && x0v;
+    t.v11 = fin && y1v && x1v;
+    return t;
+}
+
+__device__ __forceinline__ float sample_taps(const float* __restrict__ plane, const Taps& t, int W) {
+    const float* p = plane + (long)t.y0 * W + t.x0;
+    float a = t.v00 ? p[0] : 0.f;
+    float b = t.v01 ? p[1] : 0.f;
+    float c = t.v10 ? p[W] : 0.f;
+    float d = t.v11 ? p[W + 1] : 0.f;
+    // same association as ATen's CPU grid_sampler: nw*w + ne*w + sw*w + se*w
+    return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a, t.w00), __fmul_rn(b, t.w01)), __fmul_rn(c, t.w10)),
+                     __fmul_rn(d, t.w11));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace cf

@@ -1,0 +1,26 @@
+// Internal interface of the implicit-GEMM convolution (conv.hip), shared with corr.hip (all-pairs GEMM).
+#pragma once
+#include "common.h"
+
+namespace cf {
+
+struct ConvParams {
+    const float* x1;      // [B,C1,H,W]
+    const float* x2;      // [B,C2,H,W] or nullptr
+    const float* wt;      // [K][Cout] (+ b * w_bstride)
+    const float* bias;    // [Cout] or nullptr
+    const float* res;     // [B,Cout,Ho,Wo] or nullptr
+    float* out;           // [B,out_ctotal,Ho*up,Wo*up]
+    long w_bstride;
+    int C1, C2, B, H, W, Cout, KH, KW, stride, pad_h, pad_w;
+    int Ho, Wo;
+    int out_ctotal, out_coff;
+    int act;
+    float alpha;
+    int scatter2x2;       // 1: ConvTranspose k2s2 epilogue (GEMM row m = co*4 + dy*2 + dx)
+};
+
+// validates nothing; callers validate.  Returns CF_OK / CF_ERR_LAUNCH.
+int launch_conv(const ConvParams& p, hipStream_t s);
+
+}  // namespace cf

@@ -1,0 +1,251 @@
+// Small HBM-bound kernels around the convolutions: GRU gating, channel-slice copies (cat/split), TTA and
+// sliding-window accumulation, crop / pad.  One pass each, coalesced along the innermost (x) axis.
+#include "common.h"
+
+namespace cf {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& s) { g_last_error = s; }
+
+#define GRID_STRIDE(i, n) for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (n); i += (long)gridDim.x * blockDim.x)
+
+__global__ void __launch_bounds__(256) gru_reset_mul_kernel(const float* __restrict__ gates, const float* __restrict__ h,
+                                                           float* __restrict__ rh, int C, long CHW, long total) {
+    GRID_STRIDE(i, total) {
+        long b = i / CHW, r = i - b * CHW;
+        rh[i] = gates[b * 2 * CHW + r] * h[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) gru_blend_kernel(const float* __restrict__ gates, const float* __restrict__ h,
+                                                       const float* __restrict__ cand, float* __restrict__ out, long CHW,
+                                                       long total) {
+    GRID_STRIDE(i, total) {
+        long b = i / CHW, r = i - b * CHW;
+        float u = gates[b * 2 * CHW + CHW + r];
+        out[i] = (1.0f - u) * h[i] + u * cand[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) binary_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
+                                                    float* __restrict__ out, long n, long period) {
+    GRID_STRIDE(i, n) {
+        float x = a[i], y = b[period == n ? i : i % period];
+        out[i] = op == CF_OP_ADD ? x + y : (op == CF_OP_SUB ? x - y : x * y);
+    }
+}
+
+__global__ void __launch_bounds__(256) copy_channels_kernel(const float* __restrict__ src, int sct, int sco, float* __restrict__ dst,
+                                                           int dct, int dco, int C, int HW, int act, long total) {
+    GRID_STRIDE(i, total) {
+        int p = (int)(i % HW);
+        long r = i / HW;
+        int c = (int)(r % C);
+        long b = r / C;
+        dst[(b * dct + dco + c) * HW + p] = act_apply(src[(b * sct + sco + c) * HW + p], act);
+    }
+}
+
+__global__ void __launch_bounds__(256) coords_grid_kernel(float* __restrict__ out, int H, int W, long total) {
+    const int HW = H * W;
+    GRID_STRIDE(i, total) {
+        int p = (int)(i % HW);
+        int ch = (int)((i / HW) & 1);
+        out[i] = ch == 0 ? (float)(p % W) : (float)(p / W);
+    }
+}
+
+__global__ void __launch_bounds__(256) crop2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int y0,
+                                                    int x0, int h, int w, long total) {
+    GRID_STRIDE(i, total) {
+        int x = (int)(i % w);
+        long r = i / w;
+        int y = (int)(r % h);
+        long n = r / h;
+        dst[i] = src[(n * H + y0 + y) * W + x0 + x];
+    }
+}
+
+__global__ void __launch_bounds__(256) pad2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w, int y0,
+                                                   int x0, int H, int W, long total) {
+    GRID_STRIDE(i, total) {
+        int x = (int)(i % W);
+        long r = i / W;
+        int y = (int)(r % H);
+        long n = r / H;
+        int ys = y - y0, xs = x - x0;
+        dst[i] = ((unsigned)ys < (unsigned)h && (unsigned)xs < (unsigned)w) ? src[(n * h + ys) * w + xs] : 0.f;
+    }
+}
+
+// acc[b,k,y,x] += weight * softmax_k(logits[b,:,yf,xf])  with (yf,xf) the mirrored position
+__global__ void __launch_bounds__(256) tta_accumulate_kernel(const float* __restrict__ logits, float* __restrict__ acc, int K, int H,
+                                                            int W, int fh, int fw, float weight, long total) {
+    const long HW = (long)H * W;
+    GRID_STRIDE(i, total) {  // i over (b, y, x)
+        int p = (int)(i % HW);
+        long b = i / HW;
+        int y = p / W, x = p - y * W;
+        int ys = fh ? H - 1 - y : y, xs = fw ? W - 1 - x : x;
+        const float* lp = logits + b * K * HW + (long)ys * W + xs;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, lp[k * HW]);
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += expf(lp[k * HW] - mx);
+        float* ap = acc + b * K * HW + p;
+        for (int k = 0; k < K; ++k) ap[k * HW] += weight * (expf(lp[k * HW] - mx) / sum);
+    }
+}
+
+__global__ void __launch_bounds__(256) flip2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int fh,
+                                                    int fw, long total) {
+    const long HW = (long)H * W;
+    GRID_STRIDE(i, total) {
+        int p = (int)(i % HW);
+        long n = i / HW;
+        int y = p / W, x = p - y * W;
+        dst[i] = src[n * HW + (long)(fh ? H - 1 - y : y) * W + (fw ? W - 1 - x : x)];
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_accumulate_kernel(const float* __restrict__ pred, const float* __restrict__ gauss,
+                                                             float* __restrict__ agg, float* __restrict__ cnt, int X, int Y, int lx,
+                                                             int ly, int ph, int pw, long total) {
+    GRID_STRIDE(i, total) {  // i over (k, py, px)
+        int px = (int)(i % pw);
+        long r = i / pw;
+        int py = (int)(r % ph);
+        long k = r / ph;
+        float g = gauss ? gauss[py * pw + px] : 1.f;
+        long o = (k * X + lx + py) * Y + ly + px;
+        agg[o] += pred[i];  // pred already carries the Gaussian weight (mult in _internal_maybe_mirror_and_pred_2D)
+        cnt[o] += g;
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_finalize_kernel(const float* __restrict__ agg, const float* __restrict__ cnt,
+                                                           float* __restrict__ probs, uint8_t* __restrict__ seg, int K, long XY) {
+    GRID_STRIDE(i, XY) {
+        float best = -INFINITY;
+        int arg = 0;
+        for (int k = 0; k < K; ++k) {
+            float v = agg[k * XY + i] / cnt[k * XY + i];
+            probs[k * XY + i] = v;
+            if (v > best) { best = v; arg = k; }
+        }
+        seg[i] = (uint8_t)arg;
+    }
+}
+
+__global__ void __launch_bounds__(256) argmax_channels_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int K, long HW,
+                                                             long total) {
+    GRID_STRIDE(i, total) {
+        long b = i / HW, p = i - b * HW;
+        float best = -INFINITY;
+        int arg = 0;
+        for (int k = 0; k < K; ++k) {
+            float v = x[(b * K + k) * HW + p];
+            if (v > best) { best = v; arg = k; }
+        }
+        out[i] = (uint8_t)arg;
+    }
+}
+
+}  // namespace cf
+
+using namespace cf;
+
+#define LAUNCH_FLAT(kernel, n, ...)                                                                              \
+    hipLaunchKernelGGL(kernel, dim3(flat_grid((n), 256)), dim3(256), 0, as_stream(stream), __VA_ARGS__);         \
+    CF_CHECK_LAUNCH();                                                                                           \
+    return CF_OK
+
+extern "C" const char* cf_last_error(void) { return g_last_error.c_str(); }
+extern "C" int cf_version(void) { return 100; }
+
+extern "C" int cf_gru_reset_mul(const float* gates, const float* h, float* rh, int B, int C, int HW, void* stream) {
+    CF_REQUIRE(gates && h && rh, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && HW > 0, "bad shape");
+    long chw = (long)C * HW, total = (long)B * chw;
+    LAUNCH_FLAT(gru_reset_mul_kernel, total, gates, h, rh, C, chw, total);
+}
+
+extern "C" int cf_gru_blend(const float* gates, const float* h, const float* cand, float* out, int B, int C, int HW, void* stream) {
+    CF_REQUIRE(gates && h && cand && out, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && HW > 0, "bad shape");
+    long chw = (long)C * HW, total = (long)B * chw;
+    LAUNCH_FLAT(gru_blend_kernel, total, gates, h, cand, out, chw, total);
+}
+
+extern "C" int cf_binary(int op, const float* a, const float* b, float* out, long n, long b_period, void* stream) {
+    CF_REQUIRE(a && b && out, "null pointer");
+    CF_REQUIRE(n > 0 && b_period > 0 && b_period <= n && op >= CF_OP_ADD && op <= CF_OP_MUL, "bad arguments");
+    LAUNCH_FLAT(binary_kernel, n, op, a, b, out, n, b_period);
+}
+
+extern "C" int cf_copy_channels(const float* src, int src_ctotal, int src_coff, float* dst, int dst_ctotal, int dst_coff, int B,
+                                int C, int HW, int act, void* stream) {
+    CF_REQUIRE(src && dst, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && HW > 0 && src_coff >= 0 && dst_coff >= 0 && src_coff + C <= src_ctotal && dst_coff + C <= dst_ctotal,
+               "channel slice out of range");
+    CF_REQUIRE(act >= CF_ACT_NONE && act <= CF_ACT_SIGMOID, "bad activation");
+    long total = (long)B * C * HW;
+    LAUNCH_FLAT(copy_channels_kernel, total, src, src_ctotal, src_coff, dst, dst_ctotal, dst_coff, C, HW, act, total);
+}
+
+extern "C" int cf_coords_grid(float* out, int B, int H, int W, void* stream) {
+    CF_REQUIRE(out && B > 0 && H > 0 && W > 0, "bad arguments");
+    long total = (long)B * 2 * H * W;
+    LAUNCH_FLAT(coords_grid_kernel, total, out, H, W, total);
+}
+
+extern "C" int cf_crop2d(const float* src, float* dst, int N, int H, int W, int y0, int x0, int h, int w, void* stream) {
+    CF_REQUIRE(src && dst, "null pointer");
+    CF_REQUIRE(N > 0 && h > 0 && w > 0 && y0 >= 0 && x0 >= 0 && y0 + h <= H && x0 + w <= W, "crop window out of range");
+    long total = (long)N * h * w;
+    LAUNCH_FLAT(crop2d_kernel, total, src, dst, H, W, y0, x0, h, w, total);
+}
+
+extern "C" int cf_pad2d(const float* src, float* dst, int N, int h, int w, int y0, int x0, int H, int W, void* stream) {
+    CF_REQUIRE(src && dst, "null pointer");
+    CF_REQUIRE(N > 0 && h > 0 && w > 0 && y0 >= 0 && x0 >= 0 && y0 + h <= H && x0 + w <= W, "pad window out of range");
+    long total = (long)N * H * W;
+    LAUNCH_FLAT(pad2d_kernel, total, src, dst, h, w, y0, x0, H, W, total);
+}
+
+extern "C" int cf_tta_accumulate(const float* logits, float* acc, int B, int K, int H, int W, int flip_h, int flip_w, float weight,
+                                 void* stream) {
+    CF_REQUIRE(logits && acc, "null pointer");
+    CF_REQUIRE(B > 0 && K > 0 && K <= 64 && H > 0 && W > 0, "bad shape");
+    long total = (long)B * H * W;
+    LAUNCH_FLAT(tta_accumulate_kernel, total, logits, acc, K, H, W, flip_h, flip_w, weight, total);
+}
+
+extern "C" int cf_flip2d(const float* src, float* dst, int N, int H, int W, int flip_h, int flip_w, void* stream) {
+    CF_REQUIRE(src && dst && src != dst, "null or aliased pointer");
+    CF_REQUIRE(N > 0 && H > 0 && W > 0, "bad shape");
+    long total = (long)N * H * W;
+    LAUNCH_FLAT(flip2d_kernel, total, src, dst, H, W, flip_h, flip_w, total);
+}
+
+extern "C" int cf_tile_accumulate(const float* pred, const float* gauss, float* agg, float* cnt, int K, int X, int Y, int lx, int ly,
+                                  int ph, int pw, void* stream) {
+    CF_REQUIRE(pred && agg && cnt, "null pointer");
+    CF_REQUIRE(K > 0 && lx >= 0 && ly >= 0 && lx + ph <= X && ly + pw <= Y && ph > 0 && pw > 0, "tile out of range");
+    long total = (long)K * ph * pw;
+    LAUNCH_FLAT(tile_accumulate_kernel, total, pred, gauss, agg, cnt, X, Y, lx, ly, ph, pw, total);
+}
+
+extern "C" int cf_tile_finalize(const float* agg, const float* cnt, float* probs, uint8_t* seg, int K, int X, int Y, void* stream) {
+    CF_REQUIRE(agg && cnt && probs && seg, "null pointer");
+    CF_REQUIRE(K > 0 && K <= 255 && X > 0 && Y > 0, "bad shape");
+    long xy = (long)X * Y;
+    LAUNCH_FLAT(tile_finalize_kernel, xy, agg, cnt, probs, seg, K, xy);
+}
+
+extern "C" int cf_argmax_channels(const float* x, uint8_t* out, int B, int K, int HW, void* stream) {
+    CF_REQUIRE(x && out, "null pointer");
+    CF_REQUIRE(B > 0 && K > 0 && K <= 255 && HW > 0, "bad shape");
+    long total = (long)B * HW;
+    LAUNCH_FLAT(argmax_channels_kernel, total, x, out, K, (long)HW, total);
+}

@@ -1,0 +1,152 @@
+// GroupNorm / InstanceNorm (+activation, +residual) and channel-first LayerNorm.  HBM-bound.
+//
+// Statistics are accumulated in fp64 (sum, sum of squares): E[x^2]-E[x]^2 is then exact to ~1e-16 relative, so the
+// result matches PyTorch's two-pass/Welford CPU kernels to fp32 rounding.  In NCHW a (sample, group) slab is one
+// contiguous run of (C/groups)*HW floats, so the statistics pass is a plain segmented reduction.
+#include "common.h"
+
+namespace cf {
+
+// small slabs: one wave per slab, no atomics
+__global__ void __launch_bounds__(256) gn_stats_wave_kernel(const float* __restrict__ x, double* __restrict__ ws, long nslabs,
+                                                           int L) {
+    const int lane = threadIdx.x & 63;
+    long slab = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slab >= nslabs) return;
+    const float* xs = x + slab * L;
+    double s = 0.0, ss = 0.0;
+    for (int i = lane; i < L; i += 64) {
+        double v = (double)xs[i];
+        s += v;
+        ss += v * v;
+    }
+    s = wave_sum_d(s);
+    ss = wave_sum_d(ss);
+    if (lane == 0) {
+        ws[2 * slab] = s;
+        ws[2 * slab + 1] = ss;
+    }
+}
+
+// large slabs: `segs` blocks per slab, float4 loads, one fp64 atomic pair per block (ws zeroed by the caller)
+__global__ void __launch_bounds__(256) gn_stats_block_kernel(const float* __restrict__ x, double* __restrict__ ws, int L,
+                                                            int segs) {
+    const long slab = blockIdx.x / segs;
+    const int seg = blockIdx.x % segs;
+    const float* xs = x + slab * L;
+    const int L4 = L >> 2;  // L % 4 == 0 guaranteed by the host
+    const float4* x4 = reinterpret_cast<const float4*>(xs);
+    double s = 0.0, ss = 0.0;
+    for (int i = seg * 256 + threadIdx.x; i < L4; i += segs * 256) {
+        float4 v = x4[i];
+        float a = v.x + v.y, b = v.z + v.w;  // short fp32 pre-sums, then fp64
+        float qa = v.x * v.x + v.y * v.y, qb = v.z * v.z + v.w * v.w;
+        s += (double)a + (double)b;
+        ss += (double)qa + (double)qb;
+    }
+    s = wave_sum_d(s);
+    ss = wave_sum_d(ss);
+    __shared__ double red[8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[2 * w] = s; red[2 * w + 1] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = red[0] + red[2] + red[4] + red[6];
+        double tss = red[1] + red[3] + red[5] + red[7];
+        atomicAdd(&ws[2 * slab], ts);
+        atomicAdd(&ws[2 * slab + 1], tss);
+    }
+}
+
+__global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ res,
+                                                       float* __restrict__ out, const double* __restrict__ ws, int C, int HW,
+                                                       int groups, float eps, int act, int res_mode, long total) {
+    const int cpg = C / groups;
+    const double invL = 1.0 / ((double)cpg * HW);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long bc = i / HW;           // b*C + c
+        int c = (int)(bc % C);
+        long slab = bc / cpg;       // b*groups + g
+        double mean = ws[2 * slab] * invL;
+        double var = ws[2 * slab + 1] * invL - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+        float v = (x[i] - (float)mean) * rstd * g + bb;
+        if (res_mode == CF_RES_BEFORE_ACT) v += res[i];
+        v = act_apply(v, act);
+        if (res_mode == CF_RES_AFTER_ACT) v += res[i];
+        out[i] = v;
+    }
+}
+
+// LayerNorm over C of channel-first tokens: one thread per token, lanes along N (coalesced), two passes over C
+// (second pass hits L1/L2).
+__global__ void __launch_bounds__(256) layer_norm_cf_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ out, int B,
+                                                            int C, int N, float eps) {
+    const long total = (long)B * N;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        int b = (int)(t / N);
+        int n = (int)(t - (long)b * N);
+        const float* xb = x + (long)b * C * N + n;
+        float* ob = out + (long)b * C * N + n;
+        double s = 0.0, ss = 0.0;
+        for (int c = 0; c < C; ++c) {
+            double v = (double)xb[(long)c * N];
+            s += v;
+            ss += v * v;
+        }
+        double mean = s / C;
+        double var = ss / C - mean * mean;
+        if (var < 0.0) var = 0.0;
+        float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        float mf = (float)mean;
+        for (int c = 0; c < C; ++c) ob[(long)c * N] = (xb[(long)c * N] - mf) * rstd * gamma[c] + beta[c];
+    }
+}
+
+}  // namespace cf
+
+using namespace cf;
+
+extern "C" int cf_group_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,
+                             int HW, int groups, float eps, int act, int res_mode, double* ws, void* stream) {
+    CF_REQUIRE(x && out && ws, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, "bad shape B=%d C=%d HW=%d groups=%d", B, C, HW, groups);
+    CF_REQUIRE(res_mode == CF_RES_NONE || res, "residual mode %d without residual tensor", res_mode);
+    CF_REQUIRE(act >= CF_ACT_NONE && act <= CF_ACT_SIGMOID, "bad activation %d", act);
+    hipStream_t s = as_stream(stream);
+    const long nslabs = (long)B * groups;
+    const long Ll = (long)(C / groups) * HW;
+    CF_REQUIRE(Ll < (1L << 31), "slab too large");
+    const int L = (int)Ll;
+    if (L <= 4096 || (L & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) {
+        hipLaunchKernelGGL(gn_stats_wave_kernel, dim3(cdiv(nslabs, 4)), dim3(256), 0, s, x, ws, nslabs, L);
+    } else {
+        hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * nslabs, s);
+        if (e != hipSuccess) { set_error("cf_group_norm: memset failed"); return CF_ERR_LAUNCH; }
+        int segs = (int)((L / 4 + 256 * 8 - 1) / (256 * 8));  // ~8 float4 per thread
+        if (segs < 1) segs = 1;
+        if (segs > 64) segs = 64;
+        hipLaunchKernelGGL(gn_stats_block_kernel, dim3((unsigned)(nslabs * segs)), dim3(256), 0, s, x, ws, L, segs);
+    }
+    CF_CHECK_LAUNCH();
+    long total = (long)B * C * HW;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(flat_grid(total, 256, 4)), dim3(256), 0, s, x, gamma, beta, res, out, ws, C, HW, groups,
+                       eps, act, res_mode, total);
+    CF_CHECK_LAUNCH();
+    return CF_OK;
+}
+
+extern "C" int cf_layer_norm_cf(const float* x, const float* gamma, const float* beta, float* out, int B, int C, int N, float eps,
+                                void* stream) {
+    CF_REQUIRE(x && gamma && beta && out, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && N > 0, "bad shape");
+    long total = (long)B * N;
+    hipLaunchKernelGGL(layer_norm_cf_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, as_stream(stream), x, gamma, beta, out, B, C,
+                       N, eps);
+    CF_CHECK_LAUNCH();
+    return CF_OK;
+}

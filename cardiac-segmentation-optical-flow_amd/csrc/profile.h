@@ -1,0 +1,31 @@
+// Optional per-kernel timing for bench.py's roofline line: when enabled, the instrumented launches go through
+// hipExtLaunchKernelGGL with a (start, stop) event pair that brackets exactly the kernel on its own stream, and the
+// algorithmic work (flops or bytes) of each launch is recorded next to it.  Disabled (the default) it costs nothing.
+#pragma once
+#include <hip/hip_ext.h>
+
+#include "common.h"
+
+namespace cf {
+
+enum ProfileKernel {
+    PK_CONV_MT1 = 0, PK_CONV_MT2 = 1, PK_CONV_MT4 = 2,      // work = flops
+    PK_CORRVOL_S1 = 3, PK_CORRVOL_S2 = 4, PK_CORRVOL_S4 = 5, // work = algorithmic bytes
+    PK_COUNT = 6
+};
+
+bool profile_on();
+// returns false when the event pool is exhausted (the launch then goes out un-timed)
+bool profile_events(int kid, double work, hipEvent_t* start, hipEvent_t* stop);
+
+template <typename K, typename... Args>
+static inline void launch_profiled(int kid, double work, K kernel, dim3 grid, dim3 block, hipStream_t s, Args... args) {
+    hipEvent_t e0, e1;
+    if (profile_on() && profile_events(kid, work, &e0, &e1)) {
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, s, e0, e1, 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
+    }
+}
+
+}  // namespace cf

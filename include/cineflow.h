@@ -1,0 +1,179 @@
+/*
+ * cineflow.h -- C ABI of libcineflow_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (nicolas1805961/Cardiac-Segmentation-Optical-flow) has no FFI layer: its operator
+ * boundary is the `forward` of a handful of PyTorch modules.  Each entry point
+ * below replaces the device work of one such `forward` (or a fused group of them) and cites it as
+ * file:line relative to the reference root.  INTEGRATION.md shows the ctypes stub a reference maintainer
+ * would add to route those modules here.
+ *
+ * Conventions
+ *   - all tensors are caller-owned device pointers, contiguous, fp32 unless stated, NCHW ("channel-first");
+ *   - no allocation, no ownership transfer, no host synchronisation inside the library; workspaces are
+ *     passed in; every launch goes on the caller's `stream` (a hipStream_t passed as void*), so every
+ *     entry point is safe to capture in a hipGraph and to call concurrently on different streams;
+ *   - return value 0 = success, <0 = error (CF_ERR_*); cf_last_error() gives the text for the calling
+ *     thread.  Shapes are validated on the host before any launch.
+ */
+#ifndef CINEFLOW_H
+#define CINEFLOW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CF_OK 0
+#define CF_ERR_ARG (-1)     /* bad shape / null pointer / unsupported size */
+#define CF_ERR_LAUNCH (-2)  /* hipGetLastError() after a launch            */
+
+/* activation codes used by the fused epilogues */
+#define CF_ACT_NONE 0
+#define CF_ACT_GELU 1    /* exact erf GELU (torch.nn.GELU default)       */
+#define CF_ACT_RELU 2
+#define CF_ACT_LRELU 3   /* LeakyReLU(0.01), generic_UNet.py:38          */
+#define CF_ACT_TANH 4
+#define CF_ACT_SIGMOID 5
+
+/* residual placement for cf_group_norm */
+#define CF_RES_NONE 0
+#define CF_RES_BEFORE_ACT 1  /* SingleConv, lib/utils.py:1258-1261  */
+#define CF_RES_AFTER_ACT 2   /* DoubleConv, lib/utils.py:1207-1212  */
+
+const char* cf_last_error(void);
+int cf_version(void);
+
+/* ---------------------------------------------------------------- VoxelMorph warp family
+ * SpatialTransformer.forward, nnunet/network_architecture/integration.py:61-79 (2-D branch):
+ * out[b,c,i,j] = bilinear(src[b,c], i + flow[b,0,i,j], j + flow[b,1,i,j]), align_corners=True, zero padding,
+ * with the reference's normalise/un-normalise fp32 rounding path reproduced. */
+int cf_warp_bilinear_2d(const float* flow, const float* src, float* out, int B, int C, int H, int W, void* stream);
+
+/* VecInt.forward, integration.py:95-99: v = v/2^nsteps; nsteps x { v = v + warp(v, v) }.
+ * `tmp` is a caller workspace of B*2*H*W floats; result in `out` (may not alias `vec`). */
+int cf_vecint_2d(const float* vec, float* out, float* tmp, int B, int H, int W, int nsteps, void* stream);
+
+/* warp_linear, nnunet/network_architecture/SegFlowGaussian.py:3571-3580, fused:
+ * one_hot(labels, K) -> warp with flow[t] -> argmax over K (first maximum wins).
+ * flow [T,B,2,H,W]; labels uint8 [B,H,W] (ED label map, values < K <= 8); out uint8 [T,B,H,W]. */
+int cf_warp_labels_2d(const float* flow, const uint8_t* labels, uint8_t* out, int T, int B, int K, int H, int W,
+                      void* stream);
+
+/* The 6-channel memory-encoder input of SegFlowGaussian.py:1427-1433 / :1898-1904, fused:
+ * reg = warp(cum, xt); out = cat[x0, xt, cum(2), x0 - reg, reg].  x0, xt [B,1,H,W]; cum [B,2,H,W]; out [B,6,H,W]. */
+int cf_memory_input(const float* x0, const float* xt, const float* cum, float* out, int B, int H, int W, void* stream);
+
+/* jacobian_determinant, nnunet/compute_jacobian.py:16-59 (2-D branch), np.gradient semantics, float64 math.
+ * disp [B,2,H,W] channel-first (channel 0 along axis H); det float64 [B,H,W].  H,W >= 2. */
+int cf_jacobian_det_2d(const float* disp, double* det, int B, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- correlation
+ * CorrVolume(radius, stride)(cur, prev) -- source absent from the reference; call sites
+ * SegFlowGaussian.py:256-261, :1376-1377; spec in DESIGN.md ("parity unpinned"):
+ * out[b,(dy+r)(2r+1)+(dx+r),y,x] = mean_c cur[b,c,y,x] * prev[b,c,y+dy*stride,x+dx*stride], zero outside. */
+int cf_corr_volume(const float* cur, const float* prev, float* out, int B, int C, int H, int W, int radius, int stride,
+                   void* stream);
+
+/* CorrBlock (published RAFT; call site SegFlowGaussian.py:929): all-pairs volume
+ * corr[b, n1, n2] = sum_c f1[b,c,n1] f2[b,c,n2] / sqrt(C) into pyr level 0, then `levels`-1 2x2 average pools.
+ * pyr: one buffer, level l at element offset sum_{j<l} B*N*(H>>j)*(W>>j), N = H*W.  H*W % 64 == 0. */
+int cf_corr_pyramid(const float* f1, const float* f2, float* pyr, int B, int C, int H, int W, int levels, void* stream);
+
+/* CorrBlock.__call__(coords), call site SegFlowGaussian.py:935: radius-r bilinear lookup on every level.
+ * coords [B,2,H,W] (x,y); out [B, levels*(2r+1)^2, H, W]. */
+int cf_corr_lookup(const float* pyr, const float* coords, float* out, int B, int H, int W, int levels, int radius,
+                   void* stream);
+
+/* SegFlowGaussian.upsample_flow, SegFlowGaussian.py:846-857: convex 8x upsampling.
+ * flow [B,C,h,w], mask [B,576,h,w] -> out [B,C,8h,8w] (C = 2 for flow, 4 for upsample_seg :860-871). */
+int cf_convex_upsample(const float* flow, const float* mask, float* out, int B, int C, int h, int w, void* stream);
+
+/* ---------------------------------------------------------------- convolution (implicit GEMM on fp32 MFMA)
+ * nn.Conv2d forward as used by DoubleConv (lib/utils.py:1182-1215), ConvDropoutNormNonlin
+ * (generic_UNet.py:64-68), ConvGRUCell (convGRU.py:57-66), the nn.Linear / MultiheadAttention projections of
+ * TransformerFlowLayer (lib/vit_transformer.py:1253-1267, as 1x1 convs on channel-first tokens) and the RAFT
+ * update block.  The input is the channel concatenation cat[x1 (C1 ch), x2 (C2 ch)] (x2 may be NULL/0): the
+ * reference's torch.cat((skip, x), 1) never materialises.
+ *   wt    : weights pre-transposed to [K = (C1+C2)*KH*KW][Cout]  (K index = ci*KH*KW + kh*KW + kw);
+ *           w_bstride != 0 selects per-sample weights (element stride) -- used for the all-pairs GEMM
+ *   out   : written into channels [out_coff, out_coff+Cout) of a [B,out_ctotal,Ho,Wo] tensor
+ *   value : act(alpha * conv + bias[co]) + res[b,co,oy,ox]      (bias, res nullable; res is [B,Cout,Ho,Wo]) */
+int cf_conv2d(const float* x1, int C1, const float* x2, int C2, const float* wt, long w_bstride, const float* bias,
+              const float* res, float* out, int out_ctotal, int out_coff, int B, int H, int W, int Cout, int KH,
+              int KW, int stride, int pad_h, int pad_w, int act, float alpha, void* stream);
+
+/* nn.ConvTranspose2d(k=2, s=2) of PatchExpand2DGroup (lib/utils.py:1982-1994) and Generic_UNet.tu
+ * (generic_UNet.py:343-345).  w is the torch layout [Cin][Cout][2][2] (no transposition needed); bias nullable.
+ * out is written into channels [out_coff, out_coff+Cout) of a [B,out_ctotal,2H,2W] tensor. */
+int cf_conv_transpose2d_k2s2(const float* x, const float* w, const float* bias, float* out, int out_ctotal,
+                             int out_coff, int B, int Cin, int H, int W, int Cout, void* stream);
+
+/* ---------------------------------------------------------------- normalisation
+ * nn.GroupNorm(groups, C) / nn.InstanceNorm2d(C, affine) (groups == C) + activation + residual, two launches
+ * (fp64 statistics, then apply).  ws: caller workspace of 2*B*groups doubles.  gamma/beta nullable (1 / 0).
+ * out = act(gn(x) [+ res]) [+ res]  per res_mode.  In-place (out == x) allowed. */
+int cf_group_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,
+                  int HW, int groups, float eps, int act, int res_mode, double* ws, void* stream);
+
+/* nn.LayerNorm(C) over the channel axis of channel-first tokens x [B,C,N] (lib/vit_transformer.py:1257,1261,1265);
+ * the residual add is done by the preceding conv epilogue. */
+int cf_layer_norm_cf(const float* x, const float* gamma, const float* beta, float* out, int B, int C, int N, float eps,
+                     void* stream);
+
+/* ---------------------------------------------------------------- attention
+ * nn.MultiheadAttention core (need_weights path: q scaled by 1/sqrt(d) first), channel-first:
+ * q [B,heads*d,Nq], k,v [B,heads*d,Nk] with element batch strides q_bs,k_bs,v_bs (so they may be channel slices
+ * of a fused projection buffer); out [B,heads*d,Nq] contiguous.  d in {8,16,32,64}; Nq,Nk multiples of 32. */
+int cf_attention_cf(const float* q, long q_bs, const float* k, long k_bs, const float* v, long v_bs, float* out, int B,
+                    int heads, int d, int Nq, int Nk, void* stream);
+
+/* ---------------------------------------------------------------- ConvGRU gating (convGRU.py:60-68)
+ * gates [B,2C,HW] = sigmoid(conv_gates(...)) with channels [0,C) = reset, [C,2C) = update. */
+int cf_gru_reset_mul(const float* gates, const float* h, float* rh, int B, int C, int HW, void* stream);
+int cf_gru_blend(const float* gates, const float* h, const float* cand, float* out, int B, int C, int HW, void* stream);
+
+/* ---------------------------------------------------------------- small tensor plumbing kernels */
+#define CF_OP_ADD 0
+#define CF_OP_SUB 1
+#define CF_OP_MUL 2
+/* out[i] = a[i] op b[i % b_period]  (b_period = n for no broadcast) */
+int cf_binary(int op, const float* a, const float* b, float* out, long n, long b_period, void* stream);
+/* dst[b, dst_coff + c, :] = act(src[b, src_coff + c, :])  for c < C : cat / split / activation of channel slices */
+int cf_copy_channels(const float* src, int src_ctotal, int src_coff, float* dst, int dst_ctotal, int dst_coff, int B,
+                     int C, int HW, int act, void* stream);
+/* coords_grid (published RAFT; call site SegFlowGaussian.py:838-839): out [B,2,H,W], channel 0 = x, 1 = y */
+int cf_coords_grid(float* out, int B, int H, int W, void* stream);
+/* dst [N,h,w] = src [N,H,W][y0:y0+h, x0:x0+w]   (Processor.crop_data, processor.py:134-138) */
+int cf_crop2d(const float* src, float* dst, int N, int H, int W, int y0, int x0, int h, int w, void* stream);
+/* dst [N,H,W] = zero-pad of src [N,h,w] placed at (y0,x0)  (Processor.uncrop_no_registration, processor.py:178-186) */
+int cf_pad2d(const float* src, float* dst, int N, int h, int w, int y0, int x0, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- sliding-window / TTA (neural_network.py)
+ * _internal_maybe_mirror_and_pred_2D :596-615, one term: acc += weight * flip(softmax_K(flip-input logits)).
+ * logits [B,K,H,W] are the network output on the (possibly flipped) input; flips undo the mirroring. */
+int cf_tta_accumulate(const float* logits, float* acc, int B, int K, int H, int W, int flip_h, int flip_w, float weight,
+                      void* stream);
+int cf_flip2d(const float* src, float* dst, int N, int H, int W, int flip_h, int flip_w, void* stream);
+/* :711-731: agg[:, lx:lx+ph, ly:ly+pw] += pred * g ; cnt[...] += g   (g nullable = ones). pred [K,ph,pw]. */
+int cf_tile_accumulate(const float* pred, const float* gauss, float* agg, float* cnt, int K, int X, int Y, int lx,
+                       int ly, int ph, int pw, void* stream);
+/* :741-744: probs = agg/cnt ; seg = argmax_K probs (first maximum).  seg uint8 [X,Y]. */
+int cf_tile_finalize(const float* agg, const float* cnt, float* probs, uint8_t* seg, int K, int X, int Y, void* stream);
+/* argmax over K of [B,K,HW] -> uint8 [B,HW] */
+int cf_argmax_channels(const float* x, uint8_t* out, int B, int K, int HW, void* stream);
+
+/* ---------------------------------------------------------------- measurement hooks (bench.py only; no reference analogue)
+ * cf_profile_enable(n): pre-create n event pairs and time every conv / CorrVolume launch with a (start, stop) pair that
+ * brackets exactly that kernel on its own stream (hipExtLaunchKernelGGL); 0 disables.  Kernel ids:
+ * 0,1,2 = conv_igemm MT 1,2,4 (work = flops); 3,4,5 = corr_volume_r4 stride 1,2,4 (work = algorithmic bytes).
+ * cf_profile_read sums kernel durations [ms], work and launches since the last cf_profile_reset (it synchronises: call it
+ * outside the timed region). */
+int cf_profile_enable(int max_launches);
+int cf_profile_reset(void);
+int cf_profile_read(int kernel_id, double* total_ms, double* total_work, long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CINEFLOW_H */

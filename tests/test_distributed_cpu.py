@@ -1,0 +1,54 @@
+"""world_size-2 gloo test of the multi-GPU host logic (no GPU): weight broadcast as one flat buffer, the reference's
+[part_id::num_parts] patient partition, and the max-over-ranks timing reduction used by bench.py."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "cardiac-segmentation-optical-flow_amd"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from cineflow import parallel
+    from cineflow.weights import seeded_state_dict
+    r, w, _ = parallel.init_from_env(backend="gloo")
+    shapes = {"a.conv1.weight": (4, 3, 3, 3), "a.norm1.weight": (4,), "a.norm1.bias": (4,), "b.linear1.weight": (8, 4)}
+    sd = seeded_state_dict(shapes, seed=5) if r == 0 else None  # only rank 0 "reads the checkpoint"
+    got = parallel.broadcast_state_dict(sd, shapes, torch.device("cpu"))
+    want = seeded_state_dict(shapes, seed=5)
+    ok = all(torch.equal(got[k], want[k]) for k in shapes)
+    patients = list(range(7))
+    mine = parallel.shard(patients, r, w)
+    tmax = parallel.max_over_ranks(1.0 + r, torch.device("cpu"))
+    tsum = parallel.sum_over_ranks(len(mine), torch.device("cpu"))
+    parallel.barrier()
+    q.put((r, ok, mine, tmax, tsum))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1], "broadcast weights differ from rank 0's"
+    assert res[0][2] == [0, 2, 4, 6] and res[1][2] == [1, 3, 5]
+    assert res[0][3] == res[1][3] == 2.0
+    assert res[0][4] == res[1][4] == 7.0

@@ -1,0 +1,260 @@
+"""GPU parity tests of the module/model level against the golden vectors (reference outputs) and the oracle.
+
+Bars (BASELINE.json north_star): mean flow EPE <= 1e-4 px, Dice of propagated labels within 1e-3."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RED = dict(in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32])
+S = 64
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxdiff(a, b):
+    return float((a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
+
+
+def check(a, b, tol, what=""):
+    d = maxdiff(a, b)
+    assert d <= tol, "%s max|diff| %.3e > %.1e" % (what, d, tol)
+
+
+def load(mod, seed, dev):
+    from cineflow.weights import seeded_state_dict
+    mod.load_state_dict(seeded_state_dict(mod.state_shapes(), seed), dev)
+    return mod
+
+
+def randn(*shape, seed):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def test_convgru(dev, golden):
+    from cineflow.nn import ConvGRUCell
+    g = golden("convgru")
+    m = load(ConvGRUCell((8, 8), 32, 32), 1, dev)
+    check(m(T(g["x"]).to(dev), T(g["h"]).to(dev)), g["out"], 1e-5)
+
+
+@pytest.mark.parametrize("tag,kw", [("res_s1", dict(in_dim=6, out_dim=16, nb_blocks=1, residual=True)),
+                                    ("res_s2", dict(in_dim=16, out_dim=32, nb_blocks=1, residual=True, stride=2)),
+                                    ("same", dict(in_dim=16, out_dim=16, nb_blocks=1, residual=True)),
+                                    ("nores", dict(in_dim=16, out_dim=8, nb_blocks=1, residual=False)),
+                                    ("single", dict(in_dim=8, out_dim=16, nb_blocks=1, residual=True, nb_conv=1))])
+def test_convblocks(dev, golden, tag, kw):
+    from cineflow.nn import ConvBlocks2DGroupLegacy
+    g = golden("convblock_" + tag)
+    m = load(ConvBlocks2DGroupLegacy(**kw), 2, dev)
+    check(m(T(g["x"]).to(dev)), g["out"], 2e-5)
+
+
+def test_patch_expand_merge(dev, golden):
+    from cineflow.nn import PatchExpand2DGroup, PatchMerging2DGroup
+    g = golden("patchexpand")
+    check(load(PatchExpand2DGroup(32, 16), 3, dev)(T(g["x"]).to(dev)), g["out"], 2e-5)
+    g = golden("patchmerging")
+    check(load(PatchMerging2DGroup(8, 16), 3, dev)(T(g["x"]).to(dev)), g["out"], 2e-5)
+
+
+def test_encoders_decoder(dev, golden):
+    from cineflow.nn import Encoder2D, Decoder2D
+    g = golden("encoder2d")
+    m = load(Encoder2D(d_model=32, conv_depth=[1, 1, 1], in_dims=RED["in_dims"], out_dims=RED["out_encoder_dims"], nb_conv=2,
+                       extra_block=True, residual=True, downsample_conv=2), 4, dev)
+    f, sk = m(T(g["x"]).to(dev))
+    check(f, g["feat"], 5e-5)
+    for i in range(3):
+        check(sk[i], g["skip%d" % i], 5e-5)
+    g = golden("encoder_ma")
+    m = load(Encoder2D(d_model=32, conv_depth=[1, 1, 1], in_dims=[2, 16, 32], out_dims=RED["out_encoder_dims"], nb_conv=2,
+                       extra_block=False, residual=True, downsample_conv=2, motion_appearance=True), 5, dev)
+    a, mo, sk = m(T(g["x"]).to(dev))
+    check(a, g["app"], 5e-5)
+    check(mo, g["motion"], 5e-5)
+    g = golden("encoder2d_succ")
+    m = load(Encoder2D(d_model=64, conv_depth=[1, 1, 1], in_dims=RED["in_dims"], out_dims=RED["out_encoder_dims"], nb_conv=2,
+                       extra_block=False, residual=False, downsample_conv=1), 6, dev)
+    f, sk = m(T(g["x"]).to(dev))
+    check(f, g["feat"], 5e-5)
+    check(sk[2], g["skip2"], 5e-5)
+    g = golden("decoder2d")
+    m = load(Decoder2D(d_model=32, dot_multiplier=2, conv_depth=[1, 1, 1], in_encoder_dims=[32, 16, 4], out_encoder_dims=[32, 16, 8],
+                       num_classes=2, nb_conv=2, residual=True), 7, dev)
+    check(m(T(g["x"]).to(dev), [T(g["skip0"]).to(dev), T(g["skip1"]).to(dev), T(g["skip2"]).to(dev)]), g["out"], 5e-5)
+
+
+def test_posenc(dev, golden):
+    from cineflow.nn import position_embedding_sine_2d
+    pos = position_embedding_sine_2d(8, 8, 32, dev)
+    check(pos.view(1, 32, 8, 8), golden("posenc")["pos"], 1e-6)
+
+
+def test_transformers(dev, golden):
+    from cineflow.nn import CrossAttentionLayer, TransformerFlowEncoderSuccessiveNoEmb
+    g = golden("crossattn")
+    m = load(CrossAttentionLayer(32, 4, 1, 64), 8, dev)
+    check(m(T(g["q"]).to(dev), T(g["k"]).to(dev), T(g["v"]).to(dev)), g["out"], 5e-5)
+    g = golden("succ_transformer")
+    m = load(TransformerFlowEncoderSuccessiveNoEmb(64, 8, 1), 9, dev)
+    check(m(T(g["u"]).to(dev)), g["out"], 5e-5)
+
+
+def test_generic_unet_and_tta(dev, golden):
+    from cineflow.models import Generic_UNet
+    from cineflow.inference import mirror_and_predict_2d
+    g = golden("generic_unet")
+    m = load(Generic_UNet(1, 8, 4, 3), 10, dev)
+    check(m(T(g["x"]).to(dev)), g["logits"], 1e-4)
+    g = golden("tta")
+    check(mirror_and_predict_2d(m, T(g["x"]).to(dev), (0, 1), True, None), g["probs"], 2e-5)
+
+
+@pytest.mark.parametrize("tag,ma,ff", [("ma", True, 64), ("cv", False, 48)])
+def test_segflow_reference_golden(dev, golden, tag, ma, ff):
+    """The reduced-width SegFlowGaussian against the REFERENCE's output (T=4): the north-star EPE bar."""
+    from cineflow.models import SegFlowGaussian
+    from oracle import ops as OO
+    g = golden("segflow_" + tag)
+    m = load(SegFlowGaussian(image_size=S, d_model=32, bottleneck_heads=4, dim_feedforward=ff, motion_appearance=ma, **RED), 11, dev)
+    out = m(T(g["frames"]).to(dev))["backward_flow"].cpu()
+    epe = OO.mean_epe(out, g["backward_flow"])
+    assert epe <= 1e-4, "mean EPE %.3e px" % epe
+    check(out, g["backward_flow"], 5e-4)
+
+
+def test_successive_reference_golden(dev, golden):
+    from cineflow.models import OpticalFlowModelSuccessive, ModelWrap
+    from oracle import ops as OO
+    g = golden("successive")
+    m = load(ModelWrap(OpticalFlowModelSuccessive(S, 1, **RED), OpticalFlowModelSuccessive(S, 6, **RED)), 12, dev)
+    o1, o2 = m(T(g["frames"]).to(dev))
+    assert OO.mean_epe(o1["flow"].cpu(), g["flow1"]) <= 1e-4
+    assert OO.mean_epe(o2["cumulated"].cpu(), g["cumulated"]) <= 1e-4
+    gi = golden("successive_infer")
+    out = m.model1(T(gi["frames"]).to(dev), inference=True)["flow"].cpu()
+    assert OO.mean_epe(out, gi["flow"]) <= 1e-4
+
+
+def test_raft_loop_vs_oracle(dev):
+    """RAFT variant (parity unpinned: update block / CorrBlock restated from the published definition)."""
+    from cineflow.models import SegFlowGaussian
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    # 128x128 so that the 4-level pyramid of the 16x16 feature map ends at 2x2 (a 1x1 level divides by zero in RAFT's sampler)
+    kw = dict(image_size=128, in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=256, bottleneck_heads=4, dim_feedforward=64,
+              motion_appearance=False, raft=True, raft_iters=3)
+    m = load(SegFlowGaussian(**kw), 13, dev)
+    ora = fill_module_(OM.SegFlowGaussian(**kw), 13)
+    frames = randn(3, 1, 1, 128, 128, seed=38)
+    out = m(frames.to(dev))["backward_flow"].cpu()
+    with torch.no_grad():
+        ref = ora(frames)["backward_flow"]
+    assert out.shape == ref.shape == (3, 2, 1, 2, 128, 128)
+    epe = OO.mean_epe(out, ref)
+    assert epe <= 1e-4, "mean EPE %.3e px (|flow| mean %.3f)" % (epe, float(ref.abs().mean()))
+
+
+def test_full_width_blocks_vs_oracle(dev):
+    """Full-width (raft_config.yaml dims) single blocks at 256x256 against the oracle on the same seeded weights."""
+    from cineflow.nn import ConvBlocks2DGroupLegacy, CrossAttentionLayer, ConvGRUCell
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    with torch.no_grad():
+        x = randn(1, 6, 256, 256, seed=90)
+        m = load(ConvBlocks2DGroupLegacy(6, 64, 1, residual=True), 20, dev)
+        o = fill_module_(OM.ConvBlocks2DGroupLegacy(6, 64, 1, residual=True), 20)
+        check(m(x.to(dev)), o(x), 5e-5, "DoubleConv 6->64 @256")
+        x = randn(1, 128, 128, 128, seed=91)
+        m = load(ConvBlocks2DGroupLegacy(128, 256, 1, residual=True, stride=2), 21, dev)
+        o = fill_module_(OM.ConvBlocks2DGroupLegacy(128, 256, 1, residual=True, stride=2), 21)
+        check(m(x.to(dev)), o(x), 5e-5, "DoubleConv 128->256 s2")
+        q, k, v = randn(1, 256, 32, 32, seed=92), randn(1, 256, 32, 32, seed=93), randn(1, 256, 32, 32, seed=94)
+        m = load(CrossAttentionLayer(256, 4, 1, 3072), 22, dev)
+        o = fill_module_(OM.CrossAttentionLayer(256, 4, 1, 3072), 22)
+        check(m(q.to(dev), k.to(dev), v.to(dev)), o(q, k, v), 5e-5, "CrossAttentionLayer 256")
+        xg, h = randn(2, 256, 32, 32, seed=95), randn(2, 256, 32, 32, seed=96)
+        m = load(ConvGRUCell((32, 32), 256, 256), 23, dev)
+        o = fill_module_(OM.ConvGRUCell((32, 32), 256, 256), 23)
+        check(m(xg.to(dev), h.to(dev)), o(xg, h), 5e-5, "ConvGRU 256")
+
+
+def test_full_width_segflow_two_frames_vs_oracle(dev):
+    """The full raft_config.yaml model (25.3 M parameters), one recurrence step at 256x256, against the CPU oracle."""
+    from cineflow.models import SegFlowGaussian
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    for ma, ff in ((False, 2048), (True, 3072)):
+        m = load(SegFlowGaussian(image_size=256, motion_appearance=ma, dim_feedforward=ff), 30, dev)
+        ora = fill_module_(OM.SegFlowGaussian(image_size=256, motion_appearance=ma, dim_feedforward=ff), 30)
+        frames = randn(3, 1, 1, 256, 256, seed=97)
+        out = m(frames.to(dev))["backward_flow"].cpu()
+        with torch.no_grad():
+            ref = ora(frames)["backward_flow"]
+        epe = OO.mean_epe(out, ref)
+        assert epe <= 1e-4, "motion_appearance=%s: mean EPE %.3e px (|flow| mean %.3f)" % (ma, epe, float(ref.abs().mean()))
+
+
+def test_sliding_window_segmentation_vs_oracle(dev):
+    """BASELINE config 1 shapes scaled to test size: volume [1,3,70,60], patch (64,48) -> 2x2 tiles, Gaussian, 4 flips."""
+    from cineflow.models import Generic_UNet
+    from cineflow.inference import predict_3D_2Dconv_tiled
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    m = load(Generic_UNet(1, 8, 4, 3), 10, dev)
+    ora = fill_module_(OM.GenericUNet2D(1, 8, 4, 3), 10)
+    x = randn(1, 3, 70, 60, seed=98).numpy()
+    seg, prob = predict_3D_2Dconv_tiled(m, x, (64, 48), step_size=0.5, do_mirroring=True, mirror_axes=(0, 1), use_gaussian=True)
+    with torch.no_grad():
+        rseg, rprob = OM.predict_3d_2dconv_tiled(ora, x, (64, 48), step_size=0.5, do_mirroring=True, mirror_axes=(0, 1), use_gaussian=True)
+    assert seg.shape == rseg.shape == (3, 70, 60) and prob.shape == rprob.shape == (4, 3, 70, 60)
+    assert float(np.abs(prob - rprob).max()) <= 5e-5
+    for k in range(4):
+        d = OO.dice(seg, rseg, k)
+        assert np.isnan(d) or abs(d - 1.0) <= 1e-3
+    # smaller-than-patch image (padding path) and single tile (no Gaussian)
+    x = randn(1, 2, 40, 30, seed=99).numpy()
+    seg, prob = predict_3D_2Dconv_tiled(m, x, (64, 48), do_mirroring=False)
+    with torch.no_grad():
+        rseg, rprob = OM.predict_3d_2dconv_tiled(ora, x, (64, 48), do_mirroring=False)
+    assert float(np.abs(prob - rprob).max()) <= 5e-5
+
+
+def test_joint_cine_pipeline_vs_oracle(dev):
+    """BASELINE config 4 at test size: seg on every frame + two-chunk flow recurrence + label propagation."""
+    from cineflow.models import SegFlowGaussian, Generic_UNet
+    from cineflow.inference import predict_cine_slices, chunk_orders
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    kw = dict(image_size=64, in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=32, bottleneck_heads=4, dim_feedforward=48,
+              motion_appearance=False)
+    fnet = load(SegFlowGaussian(**kw), 11, dev)
+    snet = load(Generic_UNet(1, 8, 4, 3), 10, dev)
+    ofnet = fill_module_(OM.SegFlowGaussian(**kw), 11)
+    osnet = fill_module_(OM.GenericUNet2D(1, 8, 4, 3), 10)
+    Tn, B = 5, 2
+    frames = randn(Tn, B, 1, 64, 64, seed=100)
+    out = predict_cine_slices(fnet, snet, frames.to(dev))
+    with torch.no_grad():
+        probs = OM.mirror_and_predict_2d(osnet, frames.reshape(Tn * B, 1, 64, 64)).view(Tn, B, 4, 64, 64)
+        seg = probs.argmax(2)
+        flow = torch.zeros(Tn, B, 2, 64, 64)
+        for order in chunk_orders(Tn):
+            bf = ofnet(frames[order])["backward_flow"]
+            for j, t in enumerate(order[1:]):
+                flow[t] = bf[j]
+        reg = OO.warp_labels(flow, seg[0][:, None].float())[:, :, 0]
+    assert float((out["softmax"].cpu() - probs).abs().max()) <= 5e-5
+    assert OO.mean_epe(out["flow"].cpu(), flow) <= 1e-4
+    assert float((out["seg"].cpu().long() == seg).float().mean()) >= 0.9995
+    for k in range(4):
+        d = OO.dice(out["registered"].cpu().numpy(), reg.numpy(), k)
+        assert np.isnan(d) or abs(d - 1.0) <= 1e-3

@@ -1,0 +1,404 @@
+"""GPU parity tests of every C-ABI operator against the oracle (and the golden vectors produced by the reference).
+
+Tolerances: the warp family reproduces the reference's fp32 rounding path, so 2e-6 abs on O(1) data; GEMM-shaped
+ops differ from the oracle only by fp32 summation order (the MFMA is an exact fp32 fmaf chain), so 1e-5 relative to
+the operand magnitude; label maps must be identical."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxdiff(a, b):
+    return float((a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
+
+
+def check(a, b, tol, what=""):
+    d = maxdiff(a, b)
+    assert d <= tol, "%s max|diff| %.3e > %.1e" % (what, d, tol)
+
+
+def randn(*shape, seed):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+# ------------------------------------------------------------------------------------------------ warp family
+@pytest.mark.parametrize("tag", ["32", "40x24"])
+def test_warp_golden(dev, golden, tag):
+    from cineflow import ops
+    g = golden("warp_" + tag)
+    flow, src = T(g["flow"]).to(dev), T(g["src"]).to(dev)
+    check(ops.warp_bilinear(flow, src), g["warped"], 2e-6, "warp")
+    check(ops.vecint(flow, 7), g["vecint"], 1e-5, "vecint")
+
+
+def test_warp_256_golden_and_properties(dev, golden):
+    from cineflow import ops
+    from oracle import ops as OO
+    g = golden("warp_256")
+    src = randn(1, 4, 256, 256, seed=13)
+    flow = F.avg_pool2d(randn(1, 2, 288, 288, seed=12), 33, stride=1) * 120.0
+    out = ops.warp_bilinear(flow.to(dev), src.to(dev))
+    check(out[:, :, :16, :16], g["warped_corner"], 2e-6)
+    check(out[:, :, 120:136, 120:136], g["warped_center"], 2e-6)
+    assert abs(float(out.double().sum()) - float(g["checksum"])) < 1e-2
+    check(out, OO.warp_bilinear(flow, src), 2e-6)
+    # identity: zero flow returns the source up to the reference's own normalise round trip (3.8e-5 at 256, SURVEY B)
+    ident = ops.warp_bilinear(torch.zeros(1, 2, 256, 256, device=dev), src.to(dev))
+    check(ident, OO.warp_bilinear(torch.zeros(1, 2, 256, 256), src), 2e-6)
+    check(ident, src, 1e-4)
+    # linearity in the source
+    a, b = randn(1, 2, 256, 256, seed=1).to(dev), randn(1, 2, 256, 256, seed=2).to(dev)
+    f = flow.to(dev)
+    lhs = ops.warp_bilinear(f, ops.add(a, b))
+    rhs = ops.add(ops.warp_bilinear(f, a), ops.warp_bilinear(f, b))
+    check(lhs, rhs.cpu(), 1e-5)
+
+
+def test_warp_edge_cases(dev):
+    from cineflow import ops
+    from oracle import ops as OO
+    # flows that leave the image on every side, exactly-integer displacements, huge and NaN-free extremes
+    H, W = 17, 23
+    src = randn(2, 3, H, W, seed=5)
+    flow = torch.zeros(2, 2, H, W)
+    flow[0, 0] = 5.0
+    flow[0, 1] = -7.0
+    flow[1] = 40.0 * randn(2, H, W, seed=6)
+    flow[1, :, 0, 0] = 1e6
+    check(ops.warp_bilinear(flow.to(dev), src.to(dev)), OO.warp_bilinear(flow.clone(), src), 2e-5)
+
+
+def test_warp_labels(dev, golden):
+    from cineflow import ops
+    from oracle import ops as OO
+    g = golden("warp_labels")
+    flow = T(g["flow"])
+    labels = T(g["labels"])  # [B,1,H,W] float
+    out = ops.warp_labels(flow.to(dev), labels[:, 0].to(torch.uint8).to(dev))
+    ref = T(g["registered"])[:, :, 0].to(torch.uint8)
+    agree = float((out.cpu() == ref).float().mean())
+    assert agree == 1.0, agree
+    # 256x256, 4 concentric rings, smooth flow (BASELINE config 2)
+    yy, xx = np.mgrid[:256, :256]
+    rad = np.sqrt((yy - 127.5) ** 2 + (xx - 127.5) ** 2)
+    lab = np.zeros((256, 256), np.uint8)
+    for k, r in enumerate((100, 70, 40), start=1):
+        lab[rad < r] = k
+    labels = torch.from_numpy(lab)[None]
+    flow = (F.avg_pool2d(randn(1, 2, 288, 288, seed=21), 33, stride=1) * 200.0)[None]
+    out = ops.warp_labels(flow.to(dev), labels.to(dev)).cpu()
+    ref = OO.warp_labels(flow, labels[:, None].float())[:, :, 0].to(torch.uint8)
+    mism = int((out != ref).sum())
+    assert mism <= 2, "label mismatches %d (ties at class borders only)" % mism
+    for k in (1, 2, 3):
+        assert abs(OO.dice(out.numpy(), ref.numpy(), k) - 1.0) <= 1e-3
+
+
+def test_memory_input(dev):
+    from cineflow import ops
+    from oracle import ops as OO
+    B, H, W = 3, 40, 56
+    x0, xt, cum = randn(B, 1, H, W, seed=7), randn(B, 1, H, W, seed=8), 3 * randn(B, 2, H, W, seed=9)
+    out = ops.memory_input(x0.to(dev), xt.to(dev), cum.to(dev))
+    reg = OO.warp_bilinear(cum.clone(), xt)
+    check(out, torch.cat([x0, xt, cum, x0 - reg, reg], 1), 2e-6)
+
+
+def test_jacobian(dev, golden):
+    from cineflow import ops
+    from oracle import ops as OO
+    g = golden("jacobian")
+    disp = T(g["disp"]).float()  # [H,W,2]
+    det = ops.jacobian_det(disp.permute(2, 0, 1)[None].contiguous().to(dev))
+    check(det[0], OO.jacobian_determinant(disp.numpy().astype(np.float64)), 1e-12)
+    check(ops.jacobian_det(torch.zeros(2, 2, 9, 5, device=dev)), np.ones((2, 9, 5)), 0)
+    big = 4 * randn(2, 2, 256, 256, seed=10)
+    ref = np.stack([OO.jacobian_determinant(big[b].permute(1, 2, 0).numpy().astype(np.float64)) for b in range(2)])
+    check(ops.jacobian_det(big.to(dev)), ref, 1e-10)
+
+
+# ------------------------------------------------------------------------------------------------ correlation
+@pytest.mark.parametrize("C,H,W,stride", [(16, 32, 64, 1), (24, 40, 72, 2), (8, 48, 80, 4), (64, 64, 64, 1), (12, 19, 37, 4),
+                                          (5, 7, 9, 2)])
+def test_corr_volume_radius4(dev, C, H, W, stride):
+    from cineflow import ops
+    from oracle import ops as OO
+    cur, prev = randn(2, C, H, W, seed=11), randn(2, C, H, W, seed=12)
+    check(ops.corr_volume(cur.to(dev), prev.to(dev), 4, stride), OO.corr_volume(cur, prev, 4, stride), 1e-5, "corr_volume")
+
+
+def test_corr_volume_generic_and_symmetry(dev):
+    from cineflow import ops
+    from oracle import ops as OO
+    cur, prev = randn(1, 6, 20, 24, seed=13), randn(1, 6, 20, 24, seed=14)
+    check(ops.corr_volume(cur.to(dev), prev.to(dev), 2, 3), OO.corr_volume(cur, prev, 2, 3), 1e-5)
+    # size-independent property at a BASELINE level: corr(cur,prev)[d](p) == corr(prev,cur)[-d](p + d*s)
+    C, S, s = 32, 128, 2
+    a, b = randn(1, C, S, S, seed=15).to(dev), randn(1, C, S, S, seed=16).to(dev)
+    ab, ba = ops.corr_volume(a, b, 4, s).cpu(), ops.corr_volume(b, a, 4, s).cpu()
+    for (dy, dx) in [(1, 2), (-4, 4), (3, -1)]:
+        ch, chm = (dy + 4) * 9 + (dx + 4), (-dy + 4) * 9 + (-dx + 4)
+        y0, y1 = max(0, -dy * s), min(S, S - dy * s)
+        x0, x1 = max(0, -dx * s), min(S, S - dx * s)
+        lhs = ab[0, ch, y0:y1, x0:x1]
+        rhs = ba[0, chm, y0 + dy * s:y1 + dy * s, x0 + dx * s:x1 + dx * s]
+        check(lhs, rhs, 1e-5)
+
+
+def test_allpairs_pyramid_lookup(dev):
+    from cineflow import ops
+    from oracle import ops as OO
+    B, C, H, W = 2, 32, 16, 16
+    f1, f2 = randn(B, C, H, W, seed=17), randn(B, C, H, W, seed=18)
+    pyr = ops.corr_pyramid(f1.to(dev), f2.to(dev), 3)
+    ref = OO.corr_pyramid(OO.corr_allpairs(f1, f2), 3)
+    off = 0
+    for l, r in enumerate(ref):
+        n = r.numel()
+        check(pyr[off:off + n].view(r.shape), r, 2e-5, "level %d" % l)
+        off += n
+    coords = OO.coords_grid(B, H, W) + 2.5 * randn(B, 2, H, W, seed=19)
+    out = ops.corr_lookup(pyr, coords.to(dev), 3, 4)
+    check(out, OO.corr_lookup(ref, coords, 4), 2e-5, "lookup")
+    check(ops.coords_grid(B, H, W, dev), OO.coords_grid(B, H, W), 0)
+
+
+def test_convex_upsample(dev):
+    from cineflow import ops
+    from oracle import ops as OO
+    flow, mask = randn(2, 2, 8, 12, seed=20), 2 * randn(2, 576, 8, 12, seed=21)
+    check(ops.convex_upsample(flow.to(dev), mask.to(dev)), OO.convex_upsample(flow, mask), 1e-5)
+    seg = randn(1, 4, 8, 8, seed=22)
+    check(ops.convex_upsample(seg.to(dev), mask[:1, :, :, :8].contiguous().to(dev)), OO.convex_upsample(seg, mask[:1, :, :, :8]), 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # B, C1, C2, H, W, Cout, kh, kw, stride, pad
+    (2, 6, 0, 32, 32, 16, 3, 3, 1, (1, 1)),
+    (2, 16, 0, 32, 32, 32, 3, 3, 2, (1, 1)),
+    (1, 8, 8, 20, 28, 24, 3, 3, 1, (1, 1)),      # dual input (cat)
+    (3, 1, 0, 17, 13, 5, 3, 3, 1, (1, 1)),       # ragged everything, K odd
+    (2, 64, 0, 16, 16, 64, 1, 1, 1, (0, 0)),
+    (2, 16, 0, 16, 16, 40, 1, 1, 2, (0, 0)),     # strided 1x1 (residual downsample)
+    (1, 2, 0, 16, 16, 128, 7, 7, 1, (3, 3)),
+    (1, 24, 8, 12, 20, 16, 1, 5, 1, (0, 2)),
+    (1, 24, 8, 12, 20, 16, 5, 1, 1, (2, 0)),
+    (1, 96, 0, 8, 8, 160, 3, 3, 1, (1, 1)),      # Cout > 128, small map
+    (1, 33, 0, 4, 4, 70, 3, 3, 1, (1, 1)),       # 4x4 map (Generic_UNet bottleneck)
+    (2, 64, 0, 64, 64, 2, 3, 3, 1, (1, 1)),      # flow head
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(dev, case):
+    from cineflow import ops
+    B, C1, C2, H, W, Cout, kh, kw, stride, pad = case
+    x1 = randn(B, C1, H, W, seed=30)
+    x2 = randn(B, C2, H, W, seed=31) if C2 else None
+    w = randn(Cout, C1 + C2, kh, kw, seed=32) / math.sqrt((C1 + C2) * kh * kw)
+    b = randn(Cout, seed=33)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = F.conv2d(xin, w, b, stride=stride, padding=pad)
+    out = ops.conv2d(x1.to(dev), ops.prep_conv_weight(w).to(dev), b.to(dev), Cout, kh, kw, stride, pad, x2=None if x2 is None else x2.to(dev))
+    check(out, ref, 2e-5, "conv")
+    # fused epilogue: activation + residual + channel offset
+    res = randn(*ref.shape, seed=34)
+    big = torch.full((B, Cout + 3) + tuple(ref.shape[2:]), 7.0, device=dev)
+    ops.conv2d(x1.to(dev), ops.prep_conv_weight(w).to(dev), b.to(dev), Cout, kh, kw, stride, pad, x2=None if x2 is None else x2.to(dev),
+               act="gelu", res=res.to(dev), out=big, out_coff=2)
+    check(big[:, 2:2 + Cout], F.gelu(ref) + res, 2e-5, "conv epilogue")
+    assert float(big[:, :2].min()) == 7.0 and float(big[:, 2 + Cout:].max()) == 7.0
+
+
+@pytest.mark.parametrize("act", ["relu", "lrelu", "tanh", "sigmoid"])
+def test_conv_activations(dev, act):
+    from cineflow import ops
+    x, w = randn(1, 8, 9, 9, seed=35), randn(12, 8, 3, 3, seed=36) / 8
+    ref = F.conv2d(x, w, None, padding=1)
+    fn = {"relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, 0.01), "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act]
+    out = ops.conv2d(x.to(dev), ops.prep_conv_weight(w).to(dev), None, 12, 3, 3, 1, (1, 1), act=act)
+    check(out, fn(ref), 1e-5)
+
+
+def test_conv_transpose(dev):
+    from cineflow import ops
+    for (B, Cin, H, W, Cout, bias) in [(2, 32, 8, 8, 16, True), (1, 20, 5, 7, 9, False), (1, 256, 32, 32, 64, True)]:
+        x, w = randn(B, Cin, H, W, seed=37), randn(Cin, Cout, 2, 2, seed=38) / math.sqrt(Cin)
+        b = randn(Cout, seed=39) if bias else None
+        ref = F.conv_transpose2d(x, w, b, stride=2)
+        out = ops.conv_transpose2d_k2s2(x.to(dev), w.to(dev), None if b is None else b.to(dev))
+        check(out, ref, 2e-5, "convT")
+
+
+def test_conv_full_size_linearity(dev):
+    """BASELINE-size layer (64->64 @ 256x256): conv(a+b) == conv(a)+conv(b), and a centre crop matches the CPU."""
+    from cineflow import ops
+    w = randn(64, 64, 3, 3, seed=40) / 24
+    wt = ops.prep_conv_weight(w).to(dev)
+    a, b = randn(2, 64, 256, 256, seed=41).to(dev), randn(2, 64, 256, 256, seed=42).to(dev)
+    ya, yb = ops.conv2d(a, wt, None, 64, 3, 3, 1, (1, 1)), ops.conv2d(b, wt, None, 64, 3, 3, 1, (1, 1))
+    yab = ops.conv2d(ops.add(a, b), wt, None, 64, 3, 3, 1, (1, 1))
+    check(yab, ops.add(ya, yb).cpu(), 2e-4)
+    ref = F.conv2d(a[:1, :, 96:160, 96:160].cpu(), w, None, padding=1)
+    check(ya[:1, :, 97:159, 97:159], ref[:, :, 1:-1, 1:-1], 5e-5)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("B,C,H,W,groups", [(2, 16, 32, 32, 8), (1, 64, 64, 64, 8), (3, 8, 5, 7, 8), (2, 24, 16, 16, 24), (2, 480, 4, 4, 480),
+                                            (1, 64, 256, 256, 8)])
+def test_group_norm(dev, B, C, H, W, groups):
+    from cineflow import ops
+    x = 3 * randn(B, C, H, W, seed=50) + 1.5
+    g, b = 1 + 0.1 * randn(C, seed=51), 0.1 * randn(C, seed=52)
+    ref = F.group_norm(x, groups, g, b, 1e-5)
+    check(ops.group_norm(x.to(dev), g.to(dev), b.to(dev), groups), ref, 2e-5, "gn")
+    res = randn(B, C, H, W, seed=53)
+    check(ops.group_norm(x.to(dev), g.to(dev), b.to(dev), groups, act="gelu", res=res.to(dev), res_mode="after_act"), F.gelu(ref) + res, 2e-5)
+    check(ops.group_norm(x.to(dev), g.to(dev), b.to(dev), groups, act="gelu", res=res.to(dev), res_mode="before_act"), F.gelu(ref + res), 2e-5)
+    check(ops.group_norm(x.to(dev), g.to(dev), b.to(dev), groups, act="lrelu"), F.leaky_relu(ref, 0.01), 2e-5)
+
+
+def test_instance_norm_matches_torch(dev):
+    from cineflow import ops
+    x = randn(2, 12, 9, 11, seed=54)
+    g, b = 1 + 0.1 * randn(12, seed=55), 0.1 * randn(12, seed=56)
+    check(ops.group_norm(x.to(dev), g.to(dev), b.to(dev), 12), F.instance_norm(x, weight=g, bias=b, eps=1e-5), 2e-5)
+
+
+def test_zscore_whole_block(dev):
+    from cineflow.inference import normalize_intensity_
+    from oracle import ops as OO
+    x = 50 * randn(5, 1, 32, 32, seed=57) + 300
+    check(normalize_intensity_(x.clone().to(dev)), OO.normalize_intensity(x), 2e-5)
+
+
+def test_layer_norm_cf(dev):
+    from cineflow import ops
+    x = randn(3, 32, 64, seed=58) * 2 + 0.5
+    g, b = 1 + 0.1 * randn(32, seed=59), 0.1 * randn(32, seed=60)
+    ref = F.layer_norm(x.permute(0, 2, 1), (32,), g, b, 1e-5).permute(0, 2, 1)
+    check(ops.layer_norm_cf(x.to(dev), g.to(dev), b.to(dev)), ref, 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,heads,d,Nq,Nk", [(2, 4, 8, 64, 64), (1, 8, 8, 64, 64), (2, 4, 64, 256, 256), (1, 4, 64, 1024, 1024), (1, 2, 16, 32, 96),
+                                             (1, 2, 32, 160, 64)])
+def test_attention(dev, B, heads, d, Nq, Nk):
+    from cineflow import ops
+    C = heads * d
+    q, k, v = randn(B, C, Nq, seed=61), randn(B, C, Nk, seed=62), randn(B, C, Nk, seed=63)
+    qh = q.view(B, heads, d, Nq).permute(0, 1, 3, 2)
+    kh = k.view(B, heads, d, Nk).permute(0, 1, 3, 2)
+    vh = v.view(B, heads, d, Nk).permute(0, 1, 3, 2)
+    att = torch.softmax((qh / math.sqrt(d)) @ kh.transpose(-1, -2), dim=-1) @ vh
+    ref = att.permute(0, 1, 3, 2).reshape(B, C, Nq)
+    check(ops.attention_cf(q.to(dev), k.to(dev), v.to(dev), heads), ref, 2e-5, "attention")
+
+
+def test_attention_slices_and_extremes(dev):
+    from cineflow import ops
+    B, heads, d, N = 2, 4, 8, 64
+    C = heads * d
+    qkv = randn(B, 3 * C, N, seed=64).to(dev)
+    q, k, v = qkv.narrow(1, 0, C), qkv.narrow(1, C, C), qkv.narrow(1, 2 * C, C)
+    a = ops.attention_cf(q, k, v, heads)
+    b = ops.attention_cf(q.contiguous(), k.contiguous(), v.contiguous(), heads)
+    check(a, b.cpu(), 0)
+    # large logits (online-softmax rescale path): one key dominates each query
+    big = qkv.clone()
+    big[:, :2 * C] *= 30.0
+    out = ops.attention_cf(big.narrow(1, 0, C), big.narrow(1, C, C), big.narrow(1, 2 * C, C), heads)
+    qh = big[:, :C].cpu().view(B, heads, d, N).permute(0, 1, 3, 2)
+    kh = big[:, C:2 * C].cpu().view(B, heads, d, N).permute(0, 1, 3, 2)
+    vh = big[:, 2 * C:].cpu().view(B, heads, d, N).permute(0, 1, 3, 2)
+    ref = (torch.softmax((qh.double() / math.sqrt(d)) @ kh.double().transpose(-1, -2), -1) @ vh.double()).permute(0, 1, 3, 2).reshape(B, C, N)
+    check(out, ref, 5e-4)
+    assert torch.isfinite(out).all()
+    # constant V -> output equals V whatever the scores
+    vc = torch.ones(B, C, N, device=dev) * 2.5
+    check(ops.attention_cf(q, k, vc, heads), vc.cpu(), 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ plumbing kernels
+def test_gru_and_elementwise(dev):
+    from cineflow import ops
+    B, C, HW = 2, 8, 20
+    gates, h, cand = torch.sigmoid(randn(B, 2 * C, HW, seed=70)), randn(B, C, HW, seed=71), torch.tanh(randn(B, C, HW, seed=72))
+    check(ops.gru_reset_mul(gates.to(dev), h.to(dev)), gates[:, :C] * h, 1e-7)
+    u = gates[:, C:]
+    check(ops.gru_blend(gates.to(dev), h.to(dev), cand.to(dev)), (1 - u) * h + u * cand, 1e-6)
+    a, b = randn(3, 5, 7, seed=73), randn(5, 7, seed=74)
+    check(ops.add(a.to(dev), b.to(dev)), a + b, 0)
+    check(ops.sub(a.to(dev), a.to(dev)), torch.zeros_like(a), 0)
+    check(ops.mul(a.to(dev), b.to(dev)), a * b, 0)
+    src = randn(2, 6, 4, 5, seed=75)
+    dst = torch.zeros(2, 9, 4, 5, device=dev)
+    ops.copy_channels(src.to(dev), 1, 3, dst=dst, dst_coff=4, act="relu")
+    check(dst[:, 4:7], F.relu(src[:, 1:4]), 0)
+    assert float(dst[:, :4].abs().sum()) == 0 and float(dst[:, 7:].abs().sum()) == 0
+
+
+def test_crop_pad_flip(dev):
+    from cineflow import ops
+    x = randn(3, 2, 20, 30, seed=76)
+    c = ops.crop2d(x.to(dev), 3, 5, 8, 16)
+    check(c, x[..., 3:11, 5:21], 0)
+    p = ops.pad2d(c, 3, 5, 20, 30)
+    ref = torch.zeros_like(x)
+    ref[..., 3:11, 5:21] = x[..., 3:11, 5:21]
+    check(p, ref, 0)
+    check(ops.flip2d(x.to(dev), 1, 0), torch.flip(x, (2,)), 0)
+    check(ops.flip2d(x.to(dev), 0, 1), torch.flip(x, (3,)), 0)
+    check(ops.flip2d(x.to(dev), 1, 1), torch.flip(x, (2, 3)), 0)
+
+
+def test_processor_device_roundtrip(dev):
+    from cineflow.inference import Processor
+    from oracle.models import Processor as OP
+    data = randn(4, 1, 40, 40, seed=77)
+    for c in [(20, 20), (2, 3), (39, 39)]:
+        p, o = Processor(16, 40), OP(16, 40)
+        crop, pad = p.crop_and_pad(data.to(dev), c)
+        ocrop, opad = o.crop_and_pad(data, c)
+        check(crop, ocrop, 0)
+        back = p.uncrop_no_registration(crop, pad)
+        check(back, o.uncrop_no_registration(ocrop[None], opad[None])[0], 0)
+
+
+def test_tta_and_tiles(dev):
+    from cineflow import ops
+    B, K, H, W = 2, 4, 12, 10
+    logits = randn(B, K, H, W, seed=78)
+    acc = torch.zeros(B, K, H, W, device=dev)
+    ops.tta_accumulate(logits.to(dev), acc, 0, 0, 0.25)
+    ops.tta_accumulate(torch.flip(logits, (3,)).contiguous().to(dev), acc, 0, 1, 0.25)
+    ops.tta_accumulate(torch.flip(logits, (2,)).contiguous().to(dev), acc, 1, 0, 0.25)
+    ops.tta_accumulate(torch.flip(logits, (2, 3)).contiguous().to(dev), acc, 1, 1, 0.25)
+    check(acc, torch.softmax(logits, 1), 1e-6)
+    agg, cnt = torch.zeros(K, 20, 18, device=dev), torch.zeros(K, 20, 18, device=dev)
+    g = torch.rand(12, 10, generator=torch.Generator().manual_seed(79)) + 0.1
+    pred = torch.softmax(logits[0], 0) * g
+    ops.tile_accumulate(pred.to(dev), g.to(dev), agg, cnt, 3, 4)
+    ops.tile_accumulate(pred.to(dev), g.to(dev), agg, cnt, 8, 8)
+    ra, rc = torch.zeros(K, 20, 18), torch.zeros(K, 20, 18)
+    for (lx, ly) in ((3, 4), (8, 8)):
+        ra[:, lx:lx + 12, ly:ly + 10] += pred
+        rc[:, lx:lx + 12, ly:ly + 10] += g
+    check(agg, ra, 1e-6)
+    check(cnt, rc, 1e-6)
+    cnt2 = cnt.clamp(min=1e-3)
+    seg, probs = ops.tile_finalize(agg, cnt2)
+    check(probs, ra / rc.clamp(min=1e-3), 1e-5)
+    assert torch.equal(seg.cpu().long(), (ra / rc.clamp(min=1e-3)).argmax(0))
+    am = ops.argmax_channels(logits.to(dev))
+    assert torch.equal(am.cpu().long(), logits.argmax(1))
