@@ -90,7 +90,7 @@ def cpu_baseline(variant, seed, T_sample):
     from cineflow.inference import chunk_orders
     from oracle import ops as OO
     ma = variant == "raft_config"
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_threads())
     fnet = fill_module_(OM.SegFlowGaussian(image_size=256, motion_appearance=ma, dim_feedforward=3072 if ma else 2048), seed)
     snet = fill_module_(OM.GenericUNet2D(1, 32, 4, 6), seed + 1)
     frames = synthetic_cine(1, T_sample, 256, 1234)
@@ -109,6 +109,21 @@ def cpu_baseline(variant, seed, T_sample):
         dt = time.perf_counter() - t0
     return {"value": T_sample / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "1 slice x %d frames of the same workload (oracle/ CPU PyTorch fp32), %.1f s" % (T_sample, dt)}
+
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))  # a 1-GPU box gives this process a 16-core share
 
 
 def main():
@@ -143,9 +158,11 @@ def main():
         lab[rad < r] = k
     ed_labels = torch.from_numpy(lab)[None].repeat(B, 1, 1).contiguous().to(dev)
 
+    log("weights + inputs resident (rank %d/%d, B=%d, T=%d)" % (rank, world, B, T))
     for _ in range(args.warmup):
         run_step(fnet, snet, frames, ed_labels, args.seg_chunk)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        log("warm-up step done")
 
     _lib.check(h.cf_profile_enable(60000), "cf_profile_enable")
     parallel.barrier()
@@ -157,6 +174,7 @@ def main():
     parallel.barrier()
     dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt, dev)
+    log("timed region: %d steps in %.3f s" % (args.steps, dt))
 
     # ---- roofline of the dominant kernel (conv_igemm, MFMA-bound) and of the correlation kernel (HBM-bound), from the
     # per-launch event pairs recorded during the timed steps
@@ -201,7 +219,9 @@ def main():
             "roofline": roofline, "roofline_corr": roofline_corr,
         }
         if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU baseline (oracle, %d threads) ..." % host_threads())
             line["cpu_baseline"] = cpu_baseline(args.variant, 1234, args.cpu_frames)
+            log("CPU baseline done")
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -65,6 +65,10 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's).  Import it FIRST so that this
+    # process holds exactly one HIP runtime and libcineflow_hip.so binds to the one torch's allocator and streams live in;
+    # loading our library first would bring in /opt/rocm's copy and the two runtimes then fight over the device.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise CineflowLibraryError(
             "libcineflow_hip.so not found at %s.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
