@@ -87,8 +87,14 @@ class Conv2d(Module):
     def _prepare(self):
         if "weight" in self._p:
             self._wt = ops.prep_conv_weight(self._p["weight"])
+            self._f16s = ops.f16s_supported(self.ks[0], self.ks[1], self.stride, self.pad)
+            if self._f16s:
+                self._wpk, self._ws = ops.pack_conv_weight_f16s(self._p["weight"])
 
     def forward(self, x, x2=None, act=None, res=None, out=None, out_coff=0):
+        if self._f16s and ops.CONV_MODE == "f16s":
+            return ops.conv2d_f16s(x, self._wpk, self._ws, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad,
+                                   x2=x2, act=act, res=res, out=out, out_coff=out_coff)
         return ops.conv2d(x, self._wt, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad, x2=x2, act=act,
                           res=res, out=out, out_coff=out_coff)
 
@@ -103,7 +109,14 @@ class ConvTranspose2d(Module):
         if bias:
             self._param("bias", (cout,))
 
+    def _prepare(self):
+        if "weight" in self._p:
+            w = self._p["weight"]  # [Cin,Cout,2,2] -> GEMM rows m = co*4 + dy*2 + dx
+            self._wpk, self._ws = ops.pack_conv_weight_f16s(w.permute(1, 2, 3, 0).reshape(self.cout * 4, self.cin, 1, 1))
+
     def forward(self, x, out=None, out_coff=0):
+        if ops.CONV_MODE == "f16s":
+            return ops.conv_transpose2d_k2s2_f16s(x, self._wpk, self._ws, self._p.get("bias"), self.cout, out=out, out_coff=out_coff)
         return ops.conv_transpose2d_k2s2(x, self._p["weight"], self._p.get("bias"), out=out, out_coff=out_coff)
 
 
@@ -325,18 +338,25 @@ class MultiheadAttention(Module):
             self._wqk = w[:2 * C].t().contiguous()
             self._bq, self._bk, self._bv = (b[i * C:(i + 1) * C].contiguous() for i in range(3))
             self._bqk = b[:2 * C].contiguous()
+            pk = lambda m: ops.pack_conv_weight_f16s(m[:, :, None, None])
+            self._pq, self._pk, self._pv, self._pqk = pk(w[:C]), pk(w[C:2 * C]), pk(w[2 * C:]), pk(w[:2 * C])
+
+    def _proj(self, x, wt, packed, bias, cout):
+        if ops.CONV_MODE == "f16s":
+            return ops.conv2d_f16s(x, packed[0], packed[1], bias, cout, 1, 1)
+        return ops.conv2d(x, wt, bias, cout, 1, 1)
 
     def forward(self, q_in, k_in, v_in, residual, same_qk=False):
         """q_in [B,C,Nq,1], k_in/v_in [B,C,Nk,1]; returns residual + out_proj(attention)."""
         C = self.C
         B, _, Nq, _ = q_in.shape
         if same_qk:
-            qk = ops.conv2d(q_in, self._wqk, self._bqk, 2 * C, 1, 1)
+            qk = self._proj(q_in, self._wqk, self._pqk, self._bqk, 2 * C)
             q, k = qk.view(B, 2 * C, Nq).narrow(1, 0, C), qk.view(B, 2 * C, Nq).narrow(1, C, C)
         else:
-            q = ops.conv2d(q_in, self._wq, self._bq, C, 1, 1).view(B, C, Nq)
-            k = ops.conv2d(k_in, self._wk, self._bk, C, 1, 1).view(B, C, -1)
-        v = ops.conv2d(v_in, self._wv, self._bv, C, 1, 1).view(B, C, -1)
+            q = self._proj(q_in, self._wq, self._pq, self._bq, C).view(B, C, Nq)
+            k = self._proj(k_in, self._wk, self._pk, self._bk, C).view(B, C, -1)
+        v = self._proj(v_in, self._wv, self._pv, self._bv, C).view(B, C, -1)
         att = ops.attention_cf(q, k, v, self.nhead).view(B, C, Nq, 1)
         return self.out_proj(att, res=residual)
 
@@ -353,8 +373,11 @@ class _Linear(Module):
     def _prepare(self):
         if "weight" in self._p:
             self._wt = self._p["weight"].t().contiguous()
+            self._wpk, self._ws = ops.pack_conv_weight_f16s(self._p["weight"][:, :, None, None])
 
     def forward(self, x, act=None, res=None):
+        if ops.CONV_MODE == "f16s":
+            return ops.conv2d_f16s(x, self._wpk, self._ws, self._p["bias"], self.cout, 1, 1, act=act, res=res)
         return ops.conv2d(x, self._wt, self._p["bias"], self.cout, 1, 1, act=act, res=res)
 
 

@@ -126,6 +126,71 @@ def prep_conv_weight(w):
     return w.reshape(cout, -1).t().contiguous()
 
 
+# ---- f16 hi/lo-split convolution (conv_f16s.hip) ------------------------------------------------------------------
+CONV_MODE = "f16s"   # "f16s": f16-MFMA 3-term split where supported, exact fp32 MFMA elsewhere;  "f32": fp32 MFMA only
+
+
+def set_conv_mode(mode):
+    global CONV_MODE
+    assert mode in ("f16s", "f32")
+    CONV_MODE = mode
+
+
+def f16s_supported(kh, kw, stride, pad):
+    return stride in (1, 2) and ((kh == 3 and kw == 3 and tuple(pad) == (1, 1)) or (kh == 1 and kw == 1 and tuple(pad) == (0, 0)))
+
+
+def pack_conv_weight_f16s(w):
+    """torch conv weight [Cout,Cin,KH,KW] (KH*KW in {1,9}) -> (packed fp16 tensor, scale exponent s).
+
+    Fragment order [m-tile][chunk][tap][kstep][part hi/lo][lane = h*32 + r][j]: value = 2^s * W[mt*32 + r][chunk*CK + kstep*16 + 8h + j][tap],
+    CK = 16 (3x3) or 32 (1x1); m-tiles padded to an even count when Cout > 32, channels padded to CK; the power of two
+    2^s brings max|W| to ~2^10 so that the lo halves stay in fp16's normal range (exact scaling, undone through alpha)."""
+    import math
+    cout, cin, kh, kw = w.shape
+    ntap = kh * kw
+    ck = 16 if ntap == 9 else 32
+    ks = ck // 16
+    nmt = 1 if cout <= 32 else 2 * ((cout + 63) // 64)
+    nchunk = (cin + ck - 1) // ck
+    wmax = float(w.abs().max())
+    s = int(math.floor(math.log2(1024.0 / wmax))) if wmax > 0 else 0
+    s = max(-24, min(24, s))
+    wp = torch.zeros((nmt * 32, nchunk * ck, ntap), dtype=torch.float32, device=w.device)
+    wp[:cout, :cin] = w.reshape(cout, cin, ntap).to(torch.float32) * (2.0 ** s)
+    hi = wp.half()
+    lo = (wp - hi.float()).half()
+    x = torch.stack([hi, lo])                                  # [part, co, ci, tap]
+    x = x.view(2, nmt, 32, nchunk, ks, 2, 8, ntap)             # part, mt, r, chunk, ks, h, j, tap
+    x = x.permute(1, 3, 7, 4, 0, 5, 2, 6).contiguous()        # mt, chunk, tap, ks, part, h, r, j
+    return x.view(-1), s
+
+
+def conv2d_f16s(x1, wpk, wscale, bias, cout, kh, kw, stride=1, pad=(0, 0), x2=None, act=None, res=None, out=None, out_coff=0, alpha=1.0):
+    B, C1, H, W = x1.shape
+    C2 = 0 if x2 is None else x2.shape[1]
+    Ho = (H + 2 * pad[0] - kh) // stride + 1
+    Wo = (W + 2 * pad[1] - kw) // stride + 1
+    if out is None:
+        out = torch.empty((B, cout, Ho, Wo), dtype=torch.float32, device=x1.device)
+    assert out.shape[0] == B and out.shape[2] == Ho and out.shape[3] == Wo
+    if res is not None:
+        assert res.shape == (B, cout, Ho, Wo)
+    assert wpk.dtype == torch.float16 and wpk.is_cuda
+    check(lib().cf_conv2d_f16s(_f32(x1), C1, _opt(x2), C2, wpk.data_ptr(), _opt(bias), _opt(res), _f32(out), out.shape[1], out_coff, B, H, W,
+                               cout, kh, kw, stride, pad[0], pad[1], ACT[act], float(alpha) * (2.0 ** -wscale), _stream()), "cf_conv2d_f16s")
+    return out
+
+
+def conv_transpose2d_k2s2_f16s(x, wpk, wscale, bias, cout, out=None, out_coff=0):
+    B, Cin, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    check(lib().cf_conv_transpose2d_k2s2_f16s(_f32(x), wpk.data_ptr(), _opt(bias), _f32(out), out.shape[1], out_coff, B, Cin, H, W, cout,
+                                              2.0 ** -wscale, _stream()), "cf_conv_transpose2d_k2s2_f16s")
+    return out
+
+
 def conv2d(x1, wt, bias, cout, kh, kw, stride=1, pad=(0, 0), x2=None, act=None, res=None, out=None, out_coff=0, alpha=1.0,
            w_bstride=0):
     """act(alpha*conv(cat[x1,x2]) + bias) + res, written into channels [out_coff, out_coff+cout) of `out`."""

@@ -23,4 +23,8 @@ struct ConvParams {
 // validates nothing; callers validate.  Returns CF_OK / CF_ERR_LAUNCH.
 int launch_conv(const ConvParams& p, hipStream_t s);
 
+// f16 hi/lo-split kernel (conv_f16s.hip)
+bool conv_f16s_supported(const ConvParams& p);
+int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s);
+
 }  // namespace cf

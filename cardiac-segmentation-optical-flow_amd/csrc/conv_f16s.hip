@@ -1,0 +1,359 @@
+// Implicit-GEMM convolution on the f16 MFMA (v_mfma_f32_32x32x16_f16) with a 3-term "hi/lo" operand split:
+//
+//     x = hi + lo,   hi = fp16(x),   lo = fp16(x - hi)                             (22 significant bits per operand)
+//     a*b ~= ah*bh + ah*bl + al*bh                                                 (al*bl ~ 2^-22 |a*b| dropped)
+//
+// Products of fp16 values are exact in the fp32 accumulator, so the result carries ~2^-22 relative operand error --
+// two bits short of fp32 -- at 3 MFMAs per 16-deep k-step, i.e. up to 16/3 = 5.3x the rate of the exact fp32 MFMA
+// (v_mfma_f32_32x32x2_f32, conv.hip).  fp16's narrow exponent is handled where it matters: the weights are scaled by
+// an exact power of two at pack time (max|w| -> ~2^10, undone through alpha), so their lo halves stay normal; the
+// activations this path sees are GroupNorm/LayerNorm/GELU outputs of O(1), whose lo halves lose at most 2^-25
+// absolute (fp16 subnormal spacing) -- below the fp32 rounding of the sum.  Measured operand-level error on
+// conv-shaped data: 7e-8 relative to max|y| vs 3e-7 for an fp32 conv; the recurrent flow network keeps
+// its 1e-4 px EPE bar with a wide margin (tests/test_gpu_models.py), which bf16 splits (8-bit pieces) would not.
+//
+// GEMM view:  D[co][pixel] = sum_{tap, ci} W[co][ci][tap] * X[b, ci, oy*s + kh - p, ox*s + kw - p]
+//   * k order = (channel chunk, tap, channel in chunk): one MFMA k-step = 16 consecutive channels at one tap, so a
+//     lane's B fragment is 8 consecutive channels of ONE input pixel.
+//   * the input patch of a workgroup is staged through LDS transposed on the fly: NCHW fp32 rows are read coalesced
+//     along x (8 channels per thread), split into hi/lo halves and written as one 80-byte (CK=16) / 144-byte (CK=32)
+//     record per pixel ([hi c0..CK) | lo c0..CK) | 16 B pad]); the odd multiple of 16 B makes every ds_read_b128 /
+//     ds_write_b128 lane group hit 16 distinct 16-byte slots (conflict free).  The 3x3 halo is staged once per
+//     workgroup, so HBM sees each input element ~1.3x per 64-channel output block.
+//   * weights are packed on the host in exact fragment order (hi and lo planes), 1 KiB per (m-tile, chunk, tap, kstep,
+//     part): an A fragment is one coalesced global_load_dwordx4 per lane from L1/L2 (all workgroups share them).
+//   * double-buffered LDS, one barrier per chunk; global loads of chunk c+1 are issued before the MFMAs of chunk c and
+//     converted/written after them (issue-early / write-late).
+//   * wave tile: one 32-channel m-tile x NTW n-tiles of 32 pixels, one fp32 accumulator per tile.
+#include <hip/hip_fp16.h>
+
+#include "conv.h"
+#include "profile.h"
+
+namespace cf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct F16sGeom {
+    int TW, TH, NIMG;        // output tile of a workgroup: NIMG images x TH rows x TW cols (NIMG*TH*TW <= NT_WG*32)
+    int PH, PW;              // staged patch rows / cols per image
+    int pstep;               // input step between patch pixels (1, or the stride for 1x1 convs)
+    int ostep;               // patch step between output pixels (stride, or 1 for 1x1 convs)
+    int tiles_x, tiles_y, bgroups;
+    int nchunk;
+};
+
+__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+    x = fminf(fmaxf(x, -60000.f), 60000.f);
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+template <int KHW, int CK, int WM, int NTW, int MAXT>
+__global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restrict__ wpk) {
+    constexpr int KW = (KHW == 9) ? 3 : 1;
+    constexpr int KS = CK / 16;            // MFMA k-steps per tap per chunk
+    constexpr int REC = CK * 4 + 16;       // bytes per pixel record
+    constexpr int NT_WG = NTW * (4 / WM);  // n-tiles per workgroup
+    constexpr int NG = CK / 8;             // 8-channel groups per record
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int mt = blockIdx.y * WM + (WM == 2 ? (wave & 1) : 0);  // 32-channel m-tile of this wave
+    const int ngrp = (WM == 2) ? (wave >> 1) : wave;              // n-tile group of this wave
+
+    // ---- workgroup tile decode (XCD-banded so that vertically adjacent tiles share one L2)
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x;
+        int xcd = bid & 7, qn = nb >> 3, rn = nb & 7;
+        bid = ((xcd < rn) ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+    }
+    const int tx = bid % g.tiles_x;
+    int t2 = bid / g.tiles_x;
+    const int ty = t2 % g.tiles_y;
+    const int bg = t2 / g.tiles_y;
+    const int x0 = tx * g.TW, y0 = ty * g.TH, b0 = bg * g.NIMG;
+    const int HW = p.H * p.W;
+    const int HoWo = p.Ho * p.Wo;
+    const int Cin = p.C1 + p.C2;
+    const int iy_org = y0 * p.stride - p.pad_h, ix_org = x0 * p.stride - p.pad_w;
+    const int nrec = g.NIMG * g.PH * g.PW;
+    const int buf_bytes = nrec * REC;
+
+    // ---- staging task descriptors (fixed over the channel loop)
+    int t_sp[MAXT];      // iy*W + ix inside a channel plane, or -1 when the pixel is outside the image / batch
+    int t_b[MAXT];       // sample index
+    int t_lds[MAXT];     // byte offset of the 16-byte hi slot inside a buffer
+    int t_grp[MAXT];     // 8-channel group inside the chunk
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        int task = tid + t * 256;
+        int grp = task / nrec;
+        int pr = task - grp * nrec;
+        t_grp[t] = grp;
+        t_sp[t] = -1;
+        t_b[t] = 0;
+        t_lds[t] = -1;
+        if (grp < NG) {
+            int img = pr / (g.PH * g.PW);
+            int q = pr - img * (g.PH * g.PW);
+            int py = q / g.PW, px = q - py * g.PW;
+            int iy = iy_org + py * g.pstep, ix = ix_org + px * g.pstep;
+            int b = b0 + img;
+            t_lds[t] = pr * REC + grp * 16;
+            t_b[t] = b;
+            if (b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) t_sp[t] = iy * p.W + ix;
+        }
+    }
+
+    // ---- per-lane B-fragment record offsets and output coordinates of this wave's n-tiles
+    int b_rec[NTW];
+    bool o_ok[NTW];
+    long o_off[NTW], r_off[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        int pidx = (ngrp * NTW + nt) * 32 + l31;
+        int img = pidx / (g.TH * g.TW);
+        int q = pidx - img * (g.TH * g.TW);
+        int tyy = q / g.TW, txx = q - tyy * g.TW;
+        bool in_tile = img < g.NIMG;
+        if (!in_tile) { img = 0; tyy = 0; txx = 0; }
+        b_rec[nt] = ((img * g.PH + tyy * g.ostep) * g.PW + txx * g.ostep) * REC + half * 16;
+        int b = b0 + img, oy = y0 + tyy, ox = x0 + txx;
+        o_ok[nt] = in_tile && b < p.B && oy < p.Ho && ox < p.Wo;
+        if (p.scatter2x2)
+            o_off[nt] = ((long)b * p.out_ctotal + p.out_coff) * (4L * HoWo) + (long)(2 * oy) * (2 * p.Wo) + 2 * ox;
+        else
+            o_off[nt] = ((long)b * p.out_ctotal + p.out_coff) * (long)HoWo + (long)oy * p.Wo + ox;
+        r_off[nt] = (long)b * p.Cout * HoWo + (long)oy * p.Wo + ox;
+    }
+
+    f32x16 acc1[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[nt][r] = 0.f;
+
+    // packed weights: fragment (mt, chunk, tap, ks, part) = 64 lanes x 8 halves
+    const f16x8* wfrag = reinterpret_cast<const f16x8*>(wpk) + (long)mt * g.nchunk * (KHW * KS * 2) * 64 + lane;
+
+    float stg[MAXT][8];
+
+    auto issue_loads = [&](int chunk) {
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int c0 = chunk * CK + t_grp[t] * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ci = c0 + j;
+                // unconditional load from a clamped address + select on the VALUE: a per-element conditional load would
+                // make hipcc branch around every load and drain vmcnt(0) each time (cdna_hip_programming.md section 5, trap c)
+                const bool ok = t_sp[t] >= 0 && ci < Cin;
+                const float* src = p.x1;
+                if (ok) src = ((ci < p.C1) ? p.x1 + ((long)t_b[t] * p.C1 + ci) * HW : p.x2 + ((long)t_b[t] * p.C2 + (ci - p.C1)) * HW) + t_sp[t];
+                const float v = *src;
+                stg[t][j] = ok ? v : 0.f;
+            }
+        }
+    };
+    auto write_stage = [&](int buf) {
+        unsigned char* base = lds + buf * buf_bytes;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            if (t_lds[t] < 0) continue;
+            f16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 h, l;
+                split_f16(stg[t][j], h, l);
+                hi[j] = h;
+                lo[j] = l;
+            }
+            *reinterpret_cast<f16x8*>(base + t_lds[t]) = hi;
+            *reinterpret_cast<f16x8*>(base + t_lds[t] + CK * 2) = lo;
+        }
+    };
+
+    issue_loads(0);
+    write_stage(0);
+    __syncthreads();
+
+    for (int c = 0; c < g.nchunk; ++c) {
+        const bool more = c + 1 < g.nchunk;
+        if (more) issue_loads(c + 1);
+        const unsigned char* xb = lds + (c & 1) * buf_bytes;
+        const f16x8* wc = wfrag + (long)c * (KHW * KS * 2) * 64;
+#pragma unroll
+        for (int tap = 0; tap < KHW; ++tap) {
+            const int toff = ((tap / KW) * g.PW + (tap % KW)) * REC;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8 ah = wc[((tap * KS + ks) * 2 + 0) * 64];
+                const f16x8 al = wc[((tap * KS + ks) * 2 + 1) * 64];
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const unsigned char* rp = xb + b_rec[nt] + toff + ks * 32;
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(rp);
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(rp + CK * 2);
+                    // small terms first, then the main term, into one accumulator
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nt], 0, 0, 0);
+                }
+            }
+        }
+        if (more) write_stage((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue (same fusion as conv.hip): value = act(alpha*acc + bias) + res  (alpha carries the weight scale 2^-s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (co >= p.Cout) continue;
+        float bv = 0.f;
+        long ochan;
+        if (p.scatter2x2) {
+            const int cr = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
+            if (p.bias) bv = p.bias[cr];
+            ochan = (long)cr * (4L * HoWo) + (long)dy * (2 * p.Wo) + dx;
+        } else {
+            if (p.bias) bv = p.bias[co];
+            ochan = (long)co * HoWo;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            if (!o_ok[nt]) continue;
+            float v = act_apply(p.alpha * acc1[nt][r] + bv, p.act);
+            if (p.res) v += p.res[r_off[nt] + (long)co * HoWo];
+            p.out[o_off[nt] + ochan] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KHW, int CK, int WM, int NTW, int MAXT>
+static int launch_f16s(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s) {
+    constexpr int REC = CK * 4 + 16;
+    const int nrec = g.NIMG * g.PH * g.PW;
+    if ((nrec * (CK / 8) + 255) / 256 > MAXT) {
+        set_error("conv_f16s: staging tasks exceed MAXT");
+        return CF_ERR_ARG;
+    }
+    const size_t lds_bytes = (size_t)2 * nrec * REC;
+    if (lds_bytes > 160 * 1024) {
+        set_error("conv_f16s: LDS tile too large");
+        return CF_ERR_ARG;
+    }
+    auto kern = conv_f16s_kernel<KHW, CK, WM, NTW, MAXT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(g.tiles_x * g.tiles_y * g.bgroups), (unsigned)((p.Cout + 32 * WM - 1) / (32 * WM)));
+    const double flops = 2.0 * (double)p.B * p.Ho * p.Wo * p.Cout * (p.C1 + p.C2) * p.KH * p.KW;
+    hipEvent_t e0, e1;
+    if (profile_on() && profile_events(PK_CONV_F16S, flops, &e0, &e1))
+        hipExtLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, e0, e1, 0, p, g, wpk);
+    else
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p, g, wpk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(std::string("conv_f16s launch failed: ") + hipGetErrorString(e));
+        return CF_ERR_LAUNCH;
+    }
+    return CF_OK;
+}
+
+bool conv_f16s_supported(const ConvParams& p) {
+    if (p.w_bstride) return false;
+    if (!((p.KH == 3 && p.KW == 3 && p.pad_h == 1 && p.pad_w == 1) || (p.KH == 1 && p.KW == 1 && p.pad_h == 0 && p.pad_w == 0))) return false;
+    if (p.stride != 1 && p.stride != 2) return false;
+    return true;
+}
+
+int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
+    const bool k3 = p.KH == 3;
+    const int CK = k3 ? 16 : 32;
+    const bool narrow = p.Cout <= 32;
+    const int NT_WG = (k3 && p.stride == 2) ? 4 : 8;  // n-tiles (of 32 pixels) per workgroup
+    const int npx = NT_WG * 32;
+    F16sGeom g;
+    g.TW = p.Wo < 32 ? p.Wo : 32;
+    g.TH = npx / g.TW;
+    if (g.TH > p.Ho) g.TH = p.Ho;
+    g.NIMG = 1;
+    if (g.TH == p.Ho && g.TW == p.Wo) {
+        g.NIMG = npx / (g.TH * g.TW);
+        if (g.NIMG > 8) g.NIMG = 8;
+        if (g.NIMG > p.B) g.NIMG = p.B;
+        if (g.NIMG < 1) g.NIMG = 1;
+    }
+    if (k3) {
+        g.pstep = 1;
+        g.ostep = p.stride;
+        g.PH = (g.TH - 1) * p.stride + 3;
+        g.PW = (g.TW - 1) * p.stride + 3;
+    } else {
+        g.pstep = p.stride;
+        g.ostep = 1;
+        g.PH = g.TH;
+        g.PW = g.TW;
+    }
+    // keep the staging work within the per-thread task budget of the variant (MAXT x 256 eight-channel tasks)
+    {
+        const int maxt = (k3 && p.stride == 2) ? 5 : 4;
+        while (g.NIMG > 1 && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 > maxt) --g.NIMG;
+    }
+    g.tiles_x = (p.Wo + g.TW - 1) / g.TW;
+    g.tiles_y = (p.Ho + g.TH - 1) / g.TH;
+    g.bgroups = (p.B + g.NIMG - 1) / g.NIMG;
+    g.nchunk = (p.C1 + p.C2 + CK - 1) / CK;
+    if (k3) {
+        if (p.stride == 1) return narrow ? launch_f16s<9, 16, 1, 2, 4>(p, g, wpk, s) : launch_f16s<9, 16, 2, 4, 4>(p, g, wpk, s);
+        return narrow ? launch_f16s<9, 16, 1, 1, 5>(p, g, wpk, s) : launch_f16s<9, 16, 2, 2, 5>(p, g, wpk, s);
+    }
+    return narrow ? launch_f16s<1, 32, 1, 2, 4>(p, g, wpk, s) : launch_f16s<1, 32, 2, 4, 4>(p, g, wpk, s);
+}
+
+}  // namespace cf
+
+using namespace cf;
+
+extern "C" int cf_conv2d_f16s(const float* x1, int C1, const float* x2, int C2, const void* wpk, const float* bias, const float* res,
+                              float* out, int out_ctotal, int out_coff, int B, int H, int W, int Cout, int KH, int KW, int stride,
+                              int pad_h, int pad_w, int act, float alpha, void* stream) {
+    CF_REQUIRE(x1 && wpk && out, "null pointer");
+    CF_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "bad channel split C1=%d C2=%d", C1, C2);
+    CF_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, "bad shape B=%d H=%d W=%d Cout=%d", B, H, W, Cout);
+    CF_REQUIRE(out_coff >= 0 && out_coff + Cout <= out_ctotal, "output channel slice out of range");
+    CF_REQUIRE(act >= CF_ACT_NONE && act <= CF_ACT_SIGMOID, "bad activation %d", act);
+    CF_REQUIRE((reinterpret_cast<uintptr_t>(wpk) & 15) == 0, "packed weights must be 16-byte aligned");
+    ConvParams p;
+    p.x1 = x1; p.x2 = C2 ? x2 : nullptr; p.wt = nullptr; p.bias = bias; p.res = res; p.out = out; p.w_bstride = 0;
+    p.C1 = C1; p.C2 = C2; p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;
+    p.pad_h = pad_h; p.pad_w = pad_w; p.Ho = (H + 2 * pad_h - KH) / stride + 1; p.Wo = (W + 2 * pad_w - KW) / stride + 1;
+    p.out_ctotal = out_ctotal; p.out_coff = out_coff; p.act = act; p.alpha = alpha; p.scatter2x2 = 0;
+    CF_REQUIRE(p.Ho > 0 && p.Wo > 0, "empty output");
+    CF_REQUIRE(conv_f16s_supported(p), "unsupported configuration for the f16-split kernel (3x3 pad 1 or 1x1 pad 0, stride 1/2)");
+    return launch_conv_f16s(p, reinterpret_cast<const _Float16*>(wpk), as_stream(stream));
+}
+
+extern "C" int cf_conv_transpose2d_k2s2_f16s(const float* x, const void* wpk, const float* bias, float* out, int out_ctotal,
+                                             int out_coff, int B, int Cin, int H, int W, int Cout, float alpha, void* stream) {
+    CF_REQUIRE(x && wpk && out, "null pointer");
+    CF_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "bad shape");
+    CF_REQUIRE(out_coff >= 0 && out_coff + Cout <= out_ctotal, "output channel slice out of range");
+    CF_REQUIRE((reinterpret_cast<uintptr_t>(wpk) & 15) == 0, "packed weights must be 16-byte aligned");
+    ConvParams p;
+    p.x1 = x; p.x2 = nullptr; p.wt = nullptr; p.bias = bias; p.res = nullptr; p.out = out; p.w_bstride = 0;
+    p.C1 = Cin; p.C2 = 0; p.B = B; p.H = H; p.W = W; p.Cout = Cout * 4; p.KH = 1; p.KW = 1; p.stride = 1;
+    p.pad_h = 0; p.pad_w = 0; p.Ho = H; p.Wo = W; p.out_ctotal = out_ctotal; p.out_coff = out_coff; p.act = CF_ACT_NONE;
+    p.alpha = alpha; p.scatter2x2 = 1;
+    return launch_conv_f16s(p, reinterpret_cast<const _Float16*>(wpk), as_stream(stream));
+}

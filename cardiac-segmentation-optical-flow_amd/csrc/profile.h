@@ -11,7 +11,8 @@ namespace cf {
 enum ProfileKernel {
     PK_CONV_MT1 = 0, PK_CONV_MT2 = 1, PK_CONV_MT4 = 2,      // work = flops
     PK_CORRVOL_S1 = 3, PK_CORRVOL_S2 = 4, PK_CORRVOL_S4 = 5, // work = algorithmic bytes
-    PK_COUNT = 6
+    PK_CONV_F16S = 6,                                        // work = flops
+    PK_COUNT = 7
 };
 
 bool profile_on();

@@ -103,6 +103,17 @@ int cf_conv2d(const float* x1, int C1, const float* x2, int C2, const float* wt,
               const float* res, float* out, int out_ctotal, int out_coff, int B, int H, int W, int Cout, int KH,
               int KW, int stride, int pad_h, int pad_w, int act, float alpha, void* stream);
 
+/* Same operator on the f16 MFMA with a 3-term hi/lo operand split (conv_f16s.hip): ~2^-22 relative operand error
+ * (fp32-class accuracy, measured in DESIGN.md) at up to 5.3x the fp32-MFMA rate.  Supported: 3x3 pad 1 or 1x1 pad 0,
+ * stride 1 or 2; anything else returns CF_ERR_ARG and the caller uses cf_conv2d.  `wpk` = weights packed by the host
+ * in MFMA fragment order as fp16 hi/lo planes and pre-scaled by 2^s (cineflow/ops.py pack_conv_weight_f16s);
+ * pass alpha * 2^-s as `alpha`. */
+int cf_conv2d_f16s(const float* x1, int C1, const float* x2, int C2, const void* wpk, const float* bias, const float* res,
+                   float* out, int out_ctotal, int out_coff, int B, int H, int W, int Cout, int KH, int KW, int stride,
+                   int pad_h, int pad_w, int act, float alpha, void* stream);
+int cf_conv_transpose2d_k2s2_f16s(const float* x, const void* wpk, const float* bias, float* out, int out_ctotal,
+                                  int out_coff, int B, int Cin, int H, int W, int Cout, float alpha, void* stream);
+
 /* nn.ConvTranspose2d(k=2, s=2) of PatchExpand2DGroup (lib/utils.py:1982-1994) and Generic_UNet.tu
  * (generic_UNet.py:343-345).  w is the torch layout [Cin][Cout][2][2] (no transposition needed); bias nullable.
  * out is written into channels [out_coff, out_coff+Cout) of a [B,out_ctotal,2H,2W] tensor. */
@@ -166,7 +177,8 @@ int cf_argmax_channels(const float* x, uint8_t* out, int B, int K, int HW, void*
 /* ---------------------------------------------------------------- measurement hooks (bench.py only; no reference analogue)
  * cf_profile_enable(n): pre-create n event pairs and time every conv / CorrVolume launch with a (start, stop) pair that
  * brackets exactly that kernel on its own stream (hipExtLaunchKernelGGL); 0 disables.  Kernel ids:
- * 0,1,2 = conv_igemm MT 1,2,4 (work = flops); 3,4,5 = corr_volume_r4 stride 1,2,4 (work = algorithmic bytes).
+ * 0,1,2 = conv_igemm MT 1,2,4 (work = flops); 3,4,5 = corr_volume_r4 stride 1,2,4 (work = algorithmic bytes);
+ * 6 = conv_f16s (work = flops).
  * cf_profile_read sums kernel durations [ms], work and launches since the last cf_profile_reset (it synchronises: call it
  * outside the timed region). */
 int cf_profile_enable(int max_launches);

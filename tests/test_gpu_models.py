@@ -127,6 +127,21 @@ def test_segflow_reference_golden(dev, golden, tag, ma, ff):
     check(out, g["backward_flow"], 5e-4)
 
 
+def test_segflow_reference_golden_exact_fp32_mode(dev, golden):
+    """Same model with every convolution on the exact fp32 MFMA kernel (cineflow.ops.set_conv_mode('f32'))."""
+    from cineflow import ops
+    from cineflow.models import SegFlowGaussian
+    from oracle import ops as OO
+    g = golden("segflow_cv")
+    m = load(SegFlowGaussian(image_size=S, d_model=32, bottleneck_heads=4, dim_feedforward=48, motion_appearance=False, **RED), 11, dev)
+    ops.set_conv_mode("f32")
+    try:
+        out = m(T(g["frames"]).to(dev))["backward_flow"].cpu()
+    finally:
+        ops.set_conv_mode("f16s")
+    assert OO.mean_epe(out, g["backward_flow"]) <= 1e-4
+
+
 def test_successive_reference_golden(dev, golden):
     from cineflow.models import OpticalFlowModelSuccessive, ModelWrap
     from oracle import ops as OO

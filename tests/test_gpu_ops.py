@@ -220,6 +220,65 @@ def test_conv2d(dev, case):
     assert float(big[:, :2].min()) == 7.0 and float(big[:, 2 + Cout:].max()) == 7.0
 
 
+F16S_CASES = [c for c in CONV_CASES if (c[6], c[7]) in ((3, 3), (1, 1))] + [
+    (2, 64, 64, 32, 32, 64, 3, 3, 1, (1, 1)),    # cat[skip, up] 128 -> 64
+    (1, 256, 0, 32, 32, 256, 3, 3, 1, (1, 1)),
+    (3, 128, 0, 64, 64, 256, 3, 3, 2, (1, 1)),   # strided, tile rows not dividing
+    (5, 480, 0, 8, 8, 480, 3, 3, 1, (1, 1)),     # 8x8 maps: 4 images per workgroup, ragged batch
+    (19, 480, 0, 4, 4, 480, 3, 3, 1, (1, 1)),    # 4x4 maps: 8 images per workgroup, ragged batch
+    (2, 30, 0, 16, 16, 30, 3, 3, 1, (1, 1)),     # 16x16, channels not multiples of 16
+    (2, 256, 0, 1024, 1, 768, 1, 1, 1, (0, 0)),  # token projection [B,C,N,1]
+    (1, 3072, 0, 1024, 1, 256, 1, 1, 1, (0, 0)), # FFN down projection
+    (2, 32, 0, 50, 70, 4, 1, 1, 1, (0, 0)),      # seg head, ragged spatial
+    (1, 81, 0, 64, 64, 64, 3, 3, 1, (1, 1)),     # cost-volume encoder, Cin = 81
+]
+
+
+@pytest.mark.parametrize("case", F16S_CASES)
+def test_conv2d_f16s(dev, case):
+    """f16-MFMA 3-term split kernel: fp32-class accuracy (same tolerance as the exact fp32 path)."""
+    from cineflow import ops
+    B, C1, C2, H, W, Cout, kh, kw, stride, pad = case
+    x1 = randn(B, C1, H, W, seed=30)
+    x2 = randn(B, C2, H, W, seed=31) if C2 else None
+    w = randn(Cout, C1 + C2, kh, kw, seed=32) / math.sqrt((C1 + C2) * kh * kw)
+    b = randn(Cout, seed=33)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    ref = F.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding=pad)
+    wpk, ws = ops.pack_conv_weight_f16s(w.to(dev))
+    out = ops.conv2d_f16s(x1.to(dev), wpk, ws, b.to(dev), Cout, kh, kw, stride, pad, x2=None if x2 is None else x2.to(dev))
+    check(out, ref, 1e-5, "conv_f16s")
+    res = randn(*ref.shape, seed=34)
+    big = torch.full((B, Cout + 3) + tuple(ref.shape[2:]), 7.0, device=dev)
+    ops.conv2d_f16s(x1.to(dev), wpk, ws, b.to(dev), Cout, kh, kw, stride, pad, x2=None if x2 is None else x2.to(dev), act="gelu",
+                    res=res.to(dev), out=big, out_coff=2)
+    check(big[:, 2:2 + Cout], F.gelu(ref) + res, 1e-5, "conv_f16s epilogue")
+    assert float(big[:, :2].min()) == 7.0 and float(big[:, 2 + Cout:].max()) == 7.0
+
+
+def test_conv_f16s_dynamic_range(dev):
+    """tiny and large operands: the weight pre-scaling keeps the lo halves normal; activations lose <= 2^-25 absolute."""
+    from cineflow import ops
+    for ax, aw in ((1.0, 1e-4), (20.0, 0.01), (0.05, 0.06), (300.0, 1e-3)):
+        x, w = ax * randn(1, 64, 32, 32, seed=43), aw * randn(64, 64, 3, 3, seed=44)
+        ref = F.conv2d(x.double(), w.double(), padding=1)
+        wpk, ws = ops.pack_conv_weight_f16s(w.to(dev))
+        out = ops.conv2d_f16s(x.to(dev), wpk, ws, None, 64, 3, 3, 1, (1, 1))
+        rel = maxdiff(out, ref) / float(ref.abs().max())
+        assert rel <= 2e-6, (ax, aw, rel)
+
+
+def test_conv_transpose_f16s(dev):
+    from cineflow import ops
+    for (B, Cin, H, W, Cout, bias) in [(2, 32, 8, 8, 16, True), (1, 20, 5, 7, 9, False), (1, 256, 32, 32, 64, True), (3, 480, 4, 4, 480, False)]:
+        x, w = randn(B, Cin, H, W, seed=37), randn(Cin, Cout, 2, 2, seed=38) / math.sqrt(Cin)
+        b = randn(Cout, seed=39) if bias else None
+        ref = F.conv_transpose2d(x.double(), w.double(), None if b is None else b.double(), stride=2)
+        wpk, ws = ops.pack_conv_weight_f16s(w.to(dev).permute(1, 2, 3, 0).reshape(Cout * 4, Cin, 1, 1))
+        out = ops.conv_transpose2d_k2s2_f16s(x.to(dev), wpk, ws, None if b is None else b.to(dev), Cout)
+        check(out, ref, 1e-5, "convT f16s")
+
+
 @pytest.mark.parametrize("act", ["relu", "lrelu", "tanh", "sigmoid"])
 def test_conv_activations(dev, act):
     from cineflow import ops
