@@ -92,7 +92,7 @@ class Conv2d(Module):
                 self._wpk, self._ws = ops.pack_conv_weight_f16s(self._p["weight"])
 
     def forward(self, x, x2=None, act=None, res=None, out=None, out_coff=0):
-        if self._f16s and ops.CONV_MODE == "f16s":
+        if self._f16s and ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, x2, self.ks[0]):
             return ops.conv2d_f16s(x, self._wpk, self._ws, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad,
                                    x2=x2, act=act, res=res, out=out, out_coff=out_coff)
         return ops.conv2d(x, self._wt, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad, x2=x2, act=act,
@@ -115,7 +115,7 @@ class ConvTranspose2d(Module):
             self._wpk, self._ws = ops.pack_conv_weight_f16s(w.permute(1, 2, 3, 0).reshape(self.cout * 4, self.cin, 1, 1))
 
     def forward(self, x, out=None, out_coff=0):
-        if ops.CONV_MODE == "f16s":
+        if ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, None, 1):
             return ops.conv_transpose2d_k2s2_f16s(x, self._wpk, self._ws, self._p.get("bias"), self.cout, out=out, out_coff=out_coff)
         return ops.conv_transpose2d_k2s2(x, self._p["weight"], self._p.get("bias"), out=out, out_coff=out_coff)
 
@@ -342,7 +342,7 @@ class MultiheadAttention(Module):
             self._pq, self._pk, self._pv, self._pqk = pk(w[:C]), pk(w[C:2 * C]), pk(w[2 * C:]), pk(w[:2 * C])
 
     def _proj(self, x, wt, packed, bias, cout):
-        if ops.CONV_MODE == "f16s":
+        if ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, None, 1):
             return ops.conv2d_f16s(x, packed[0], packed[1], bias, cout, 1, 1)
         return ops.conv2d(x, wt, bias, cout, 1, 1)
 
@@ -376,7 +376,7 @@ class _Linear(Module):
             self._wpk, self._ws = ops.pack_conv_weight_f16s(self._p["weight"][:, :, None, None])
 
     def forward(self, x, act=None, res=None):
-        if ops.CONV_MODE == "f16s":
+        if ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, None, 1):
             return ops.conv2d_f16s(x, self._wpk, self._ws, self._p["bias"], self.cout, 1, 1, act=act, res=res)
         return ops.conv2d(x, self._wt, self._p["bias"], self.cout, 1, 1, act=act, res=res)
 

@@ -140,6 +140,17 @@ def f16s_supported(kh, kw, stride, pad):
     return stride in (1, 2) and ((kh == 3 and kw == 3 and tuple(pad) == (1, 1)) or (kh == 1 and kw == 1 and tuple(pad) == (0, 0)))
 
 
+def f16s_dynamic_ok(x1, x2, kh):
+    """Run-time limits of conv_f16s.hip: a channel chunk (16 for 3x3, 32 for 1x1) must not straddle cat[x1, x2], and the
+    inputs are addressed with 32-bit buffer offsets (< 2 GiB each).  Otherwise the caller uses the exact fp32 kernel."""
+    ck = 16 if kh == 3 else 32
+    if x2 is not None and x1.shape[1] % ck:
+        return False
+    if x1.numel() * 4 >= 2 ** 31 or (x2 is not None and x2.numel() * 4 >= 2 ** 31):
+        return False
+    return True
+
+
 def pack_conv_weight_f16s(w):
     """torch conv weight [Cout,Cin,KH,KW] (KH*KW in {1,9}) -> (packed fp16 tensor, scale exponent s).
 

@@ -26,6 +26,7 @@
 //     converted/written after them (issue-early / write-late).
 //   * wave tile: one 32-channel m-tile x NTW n-tiles of 32 pixels, one fp32 accumulator per tile.
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 #include "conv.h"
 #include "profile.h"
@@ -45,7 +46,7 @@ struct F16sGeom {
 };
 
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
-    x = fminf(fmaxf(x, -60000.f), 60000.f);
+    x = __builtin_amdgcn_fmed3f(x, -60000.f, 60000.f);  // one v_med3_f32: keeps huge inputs finite in fp16
     hi = (_Float16)x;
     lo = (_Float16)(x - (float)hi);
 }
@@ -84,20 +85,25 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
     const int nrec = g.NIMG * g.PH * g.PW;
     const int buf_bytes = nrec * REC;
 
-    // ---- staging task descriptors (fixed over the channel loop)
-    int t_sp[MAXT];      // iy*W + ix inside a channel plane, or -1 when the pixel is outside the image / batch
-    int t_b[MAXT];       // sample index
-    int t_lds[MAXT];     // byte offset of the 16-byte hi slot inside a buffer
-    int t_grp[MAXT];     // 8-channel group inside the chunk
+    // ---- staging task descriptors (fixed over the channel loop).  Inputs are read with raw buffer loads: the per-lane
+    // 32-bit byte offset of (sample, channel 0, iy, ix) is computed once per task, the channel term is added per load,
+    // and the descriptor's range check returns 0 for (a) pixels outside the image / batch, whose offset is parked at
+    // 2 GiB, and (b) channel reads past the end of the tensor.  (Channels >= Cin that still fall inside the tensor read
+    // finite data of the next sample; their packed weights are exactly zero.)  Host checks: tensors < 2 GiB, and
+    // C1 % CK == 0 when x2 is present so a chunk never straddles the two inputs.
+    constexpr unsigned OOB = 0x80000000u;
+    unsigned t_o1[MAXT], t_o2[MAXT];  // byte offsets into x1 / x2 (OOB when invalid)
+    int t_lds[MAXT];                  // byte offset of the 16-byte hi slot inside a buffer, -1: no task
+    unsigned t_g8[MAXT];              // (8-channel group inside the chunk) * 8
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         int task = tid + t * 256;
         int grp = task / nrec;
         int pr = task - grp * nrec;
-        t_grp[t] = grp;
-        t_sp[t] = -1;
-        t_b[t] = 0;
+        t_o1[t] = OOB;
+        t_o2[t] = OOB;
         t_lds[t] = -1;
+        t_g8[t] = 0;
         if (grp < NG) {
             int img = pr / (g.PH * g.PW);
             int q = pr - img * (g.PH * g.PW);
@@ -105,10 +111,18 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
             int iy = iy_org + py * g.pstep, ix = ix_org + px * g.pstep;
             int b = b0 + img;
             t_lds[t] = pr * REC + grp * 16;
-            t_b[t] = b;
-            if (b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) t_sp[t] = iy * p.W + ix;
+            t_g8[t] = grp * 8;
+            if (b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+                const unsigned sp = (unsigned)(iy * p.W + ix);
+                t_o1[t] = ((unsigned)b * p.C1 * HW + sp) * 4u;
+                t_o2[t] = ((unsigned)b * p.C2 * HW + sp) * 4u;
+            }
         }
     }
+    const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x1), 0, (int)((long)p.B * p.C1 * HW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x2 ? p.x2 : p.x1), 0, p.x2 ? (int)((long)p.B * p.C2 * HW * 4) : 0, 0x00020000);
+    const unsigned HW4 = (unsigned)HW * 4u;
 
     // ---- per-lane B-fragment record offsets and output coordinates of this wave's n-tiles
     int b_rec[NTW];
@@ -143,25 +157,28 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
 
     float stg[MAXT][8];
 
+    // Loads are unconditional (clamped address, select on the VALUE): a per-element conditional load would make hipcc
+    // branch around every load and drain vmcnt(0) each time (cdna_hip_programming.md section 5, trap c).  C1 % 8 == 0 is
+    // required when x2 is present (host-checked), so an 8-channel group never straddles the two inputs.
+    // The loaded values stay RAW in registers across the MFMA section (nothing consumes a load result early), and are
+    // split into fp16 hi/lo at write time.
     auto issue_loads = [&](int chunk) {
+        const int c0 = chunk * CK;
+        const bool in1 = c0 < p.C1;                       // workgroup-uniform
+        const unsigned cb = (unsigned)(in1 ? c0 : c0 - p.C1);
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
-            const int c0 = chunk * CK + t_grp[t] * 8;
+            const unsigned v0 = (in1 ? t_o1[t] : t_o2[t]) + (cb + t_g8[t]) * HW4;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int ci = c0 + j;
-                // unconditional load from a clamped address + select on the VALUE: a per-element conditional load would
-                // make hipcc branch around every load and drain vmcnt(0) each time (cdna_hip_programming.md section 5, trap c)
-                const bool ok = t_sp[t] >= 0 && ci < Cin;
-                const float* src = p.x1;
-                if (ok) src = ((ci < p.C1) ? p.x1 + ((long)t_b[t] * p.C1 + ci) * HW : p.x2 + ((long)t_b[t] * p.C2 + (ci - p.C1)) * HW) + t_sp[t];
-                const float v = *src;
-                stg[t][j] = ok ? v : 0.f;
+                const unsigned off = v0 + (unsigned)j * HW4;
+                const unsigned raw = in1 ? __builtin_amdgcn_raw_buffer_load_b32(rsrc1, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b32(rsrc2, off, 0, 0);
+                stg[t][j] = __builtin_bit_cast(float, raw);
             }
         }
     };
-    auto write_stage = [&](int buf) {
-        unsigned char* base = lds + buf * buf_bytes;
+    auto write_stage = [&](int chunk) {
+        unsigned char* base = lds + (chunk & 1) * buf_bytes;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             if (t_lds[t] < 0) continue;
@@ -178,35 +195,53 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
         }
     };
 
+    // A-fragment register ring.  vmcnt retires in issue order, so a wait for an A fragment also waits for every staging
+    // load issued before it: the ring is prefetched D steps ahead so that the fragments consumed during the first D+1
+    // steps of a chunk were issued BEFORE that chunk's staging loads, which leaves those loads D+1 MFMA steps (plus the
+    // co-resident wave's) to land before the first wait that covers them.  NSTEP % R == 0 keeps the slots static.
+    constexpr int NSTEP = KHW * KS;
+    constexpr int R = (NSTEP % 3 == 0) ? 3 : 2;
+    constexpr int D = R - 1;
+    f16x8 aH[R], aL[R];
+    auto load_a = [&](int chunk, int step, int slot) {
+        const f16x8* wc = wfrag + ((long)chunk * NSTEP + step) * 2 * 64;
+        aH[slot] = wc[0];
+        aL[slot] = wc[64];
+    };
+
     issue_loads(0);
+#pragma unroll
+    for (int sidx = 0; sidx < D; ++sidx) load_a(0, sidx, sidx % R);
     write_stage(0);
     __syncthreads();
 
     for (int c = 0; c < g.nchunk; ++c) {
         const bool more = c + 1 < g.nchunk;
-        if (more) issue_loads(c + 1);
         const unsigned char* xb = lds + (c & 1) * buf_bytes;
-        const f16x8* wc = wfrag + (long)c * (KHW * KS * 2) * 64;
 #pragma unroll
-        for (int tap = 0; tap < KHW; ++tap) {
+        for (int step = 0; step < NSTEP; ++step) {
+            const int tap = step / KS, ks = step % KS;
+            // prefetch the fragments of step + D (possibly the next chunk's first steps)
+            if (step + D < NSTEP) load_a(c, step + D, (step + D) % R);
+            else if (more) load_a(c + 1, step + D - NSTEP, (step + D) % R);
+            if (step == 0) {
+                if (more) issue_loads(c + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             const int toff = ((tap / KW) * g.PW + (tap % KW)) * REC;
+            const f16x8 ah = aH[step % R], al = aL[step % R];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const f16x8 ah = wc[((tap * KS + ks) * 2 + 0) * 64];
-                const f16x8 al = wc[((tap * KS + ks) * 2 + 1) * 64];
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    const unsigned char* rp = xb + b_rec[nt] + toff + ks * 32;
-                    const f16x8 bh = *reinterpret_cast<const f16x8*>(rp);
-                    const f16x8 bl = *reinterpret_cast<const f16x8*>(rp + CK * 2);
-                    // small terms first, then the main term, into one accumulator
-                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
-                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
-                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nt], 0, 0, 0);
-                }
+            for (int nt = 0; nt < NTW; ++nt) {
+                const unsigned char* rp = xb + b_rec[nt] + toff + ks * 32;
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(rp);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(rp + CK * 2);
+                // small terms first, then the main term, into one accumulator
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nt], 0, 0, 0);
             }
         }
-        if (more) write_stage((c + 1) & 1);
+        if (more) write_stage(c + 1);
         __syncthreads();
     }
 
@@ -274,14 +309,30 @@ bool conv_f16s_supported(const ConvParams& p) {
     if (p.w_bstride) return false;
     if (!((p.KH == 3 && p.KW == 3 && p.pad_h == 1 && p.pad_w == 1) || (p.KH == 1 && p.KW == 1 && p.pad_h == 0 && p.pad_w == 0))) return false;
     if (p.stride != 1 && p.stride != 2) return false;
+    const int ck = (p.KH == 3) ? 16 : 32;
+    if (p.C2 > 0 && (p.C1 % ck)) return false;  // a channel chunk must not straddle x1 | x2
+    const long HW = (long)p.H * p.W;
+    if ((long)p.B * p.C1 * HW * 4 >= (1L << 31) || (long)p.B * p.C2 * HW * 4 >= (1L << 31)) return false;  // 32-bit buffer offsets
     return true;
+}
+
+static int f16s_small_tile() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CF_F16S_SMALL_TILE");
+        v = e ? atoi(e) : 1;  // default: 128-pixel workgroup tiles (4 waves/SIMD hide the staging latency; A/B in DESIGN.md)
+    }
+    return v;
 }
 
 int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
     const bool k3 = p.KH == 3;
     const int CK = k3 ? 16 : 32;
     const bool narrow = p.Cout <= 32;
-    const int NT_WG = (k3 && p.stride == 2) ? 4 : 8;  // n-tiles (of 32 pixels) per workgroup
+    const bool small = f16s_small_tile() && !narrow;
+    const bool s2 = k3 && p.stride == 2;
+    // n-tiles (of 32 output pixels) per workgroup
+    const int NT_WG = s2 ? (small ? 2 : 4) : (small ? 4 : 8);
     const int npx = NT_WG * 32;
     F16sGeom g;
     g.TW = p.Wo < 32 ? p.Wo : 32;
@@ -307,13 +358,15 @@ int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
     }
     // keep the staging work within the per-thread task budget of the variant (MAXT x 256 eight-channel tasks)
     {
-        const int maxt = (k3 && p.stride == 2) ? 5 : 4;
+        const int maxt = small ? (s2 ? 3 : 2) : (s2 ? 5 : 4);
         while (g.NIMG > 1 && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 > maxt) --g.NIMG;
     }
     g.tiles_x = (p.Wo + g.TW - 1) / g.TW;
     g.tiles_y = (p.Ho + g.TH - 1) / g.TH;
     g.bgroups = (p.B + g.NIMG - 1) / g.NIMG;
     g.nchunk = (p.C1 + p.C2 + CK - 1) / CK;
+    if (small && s2) return launch_f16s<9, 16, 2, 1, 3>(p, g, wpk, s);
+    if (small) return k3 ? launch_f16s<9, 16, 2, 2, 2>(p, g, wpk, s) : launch_f16s<1, 32, 2, 2, 2>(p, g, wpk, s);
     if (k3) {
         if (p.stride == 1) return narrow ? launch_f16s<9, 16, 1, 2, 4>(p, g, wpk, s) : launch_f16s<9, 16, 2, 4, 4>(p, g, wpk, s);
         return narrow ? launch_f16s<9, 16, 1, 1, 5>(p, g, wpk, s) : launch_f16s<9, 16, 2, 2, 5>(p, g, wpk, s);

@@ -58,16 +58,69 @@ __global__ void __launch_bounds__(256) gn_stats_block_kernel(const float* __rest
     }
 }
 
+// Apply pass.  A block works inside ONE (sample, channel) plane, so mean / rstd / gamma / beta are block-uniform scalars
+// (computed once per block from the fp64 sums) and the element loop is a pure float4 stream: y = act((x-mean)*rstd*g+b [+res]) [+res].
+template <bool VEC>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ res,
                                                        float* __restrict__ out, const double* __restrict__ ws, int C, int HW,
-                                                       int groups, float eps, int act, int res_mode, long total) {
+                                                       int groups, float eps, int act, int res_mode, int segs) {
+    const long plane = blockIdx.x / segs;  // b*C + c
+    const int seg = blockIdx.x % segs;
+    const int c = (int)(plane % C);
+    const int cpg = C / groups;
+    const long slab = plane / cpg;  // b*groups + g
+    const double invL = 1.0 / ((double)cpg * HW);
+    const double mean_d = ws[2 * slab] * invL;
+    double var = ws[2 * slab + 1] * invL - mean_d * mean_d;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mean = (float)mean_d;
+    const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+    const long base = plane * HW;
+    if (VEC) {
+        const int n4 = HW >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(x + base);
+        const float4* r4 = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
+        float4* o4 = reinterpret_cast<float4*>(out + base);
+        for (int i = seg * 256 + threadIdx.x; i < n4; i += segs * 256) {
+            float4 v = x4[i];
+            float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (res_mode != CF_RES_NONE) r = r4[i];
+            float t[4] = {v.x, v.y, v.z, v.w};
+            const float rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float y = (t[k] - mean) * rstd * g + bb;
+                if (res_mode == CF_RES_BEFORE_ACT) y += rr[k];
+                y = act_apply(y, act);
+                if (res_mode == CF_RES_AFTER_ACT) y += rr[k];
+                t[k] = y;
+            }
+            o4[i] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    } else {
+        for (int i = seg * 256 + threadIdx.x; i < HW; i += segs * 256) {
+            float y = (x[base + i] - mean) * rstd * g + bb;
+            if (res_mode == CF_RES_BEFORE_ACT) y += res[base + i];
+            y = act_apply(y, act);
+            if (res_mode == CF_RES_AFTER_ACT) y += res[base + i];
+            out[base + i] = y;
+        }
+    }
+}
+
+// small planes (HW < 2048): one thread per element, statistics looked up per element
+__global__ void __launch_bounds__(256) gn_apply_flat_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ res,
+                                                            float* __restrict__ out, const double* __restrict__ ws, int C, int HW,
+                                                            int groups, float eps, int act, int res_mode, long total) {
     const int cpg = C / groups;
     const double invL = 1.0 / ((double)cpg * HW);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long bc = i / HW;           // b*C + c
+        long bc = i / HW;
         int c = (int)(bc % C);
-        long slab = bc / cpg;       // b*groups + g
+        long slab = bc / cpg;
         double mean = ws[2 * slab] * invL;
         double var = ws[2 * slab + 1] * invL - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -133,9 +186,25 @@ extern "C" int cf_group_norm(const float* x, const float* gamma, const float* be
         hipLaunchKernelGGL(gn_stats_block_kernel, dim3((unsigned)(nslabs * segs)), dim3(256), 0, s, x, ws, L, segs);
     }
     CF_CHECK_LAUNCH();
-    long total = (long)B * C * HW;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(flat_grid(total, 256, 4)), dim3(256), 0, s, x, gamma, beta, res, out, ws, C, HW, groups,
-                       eps, act, res_mode, total);
+    if (HW < 2048) {
+        long total = (long)B * C * HW;
+        hipLaunchKernelGGL(gn_apply_flat_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, s, x, gamma, beta, res, out, ws, C, HW, groups, eps,
+                           act, res_mode, total);
+        CF_CHECK_LAUNCH();
+        return CF_OK;
+    }
+    const long planes = (long)B * C;
+    const bool vec = (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res)) & 15) == 0;
+    const int per_block = vec ? 256 * 4 * 4 : 256 * 4;  // ~4 vector (or scalar) elements per thread
+    int asegs = (HW + per_block - 1) / per_block;
+    if (asegs < 1) asegs = 1;
+    CF_REQUIRE(planes * asegs < (1L << 31), "grid too large");
+    if (vec)
+        hipLaunchKernelGGL((gn_apply_kernel<true>), dim3((unsigned)(planes * asegs)), dim3(256), 0, s, x, gamma, beta, res, out, ws, C, HW, groups,
+                           eps, act, res_mode, asegs);
+    else
+        hipLaunchKernelGGL((gn_apply_kernel<false>), dim3((unsigned)(planes * asegs)), dim3(256), 0, s, x, gamma, beta, res, out, ws, C, HW, groups,
+                           eps, act, res_mode, asegs);
     CF_CHECK_LAUNCH();
     return CF_OK;
 }

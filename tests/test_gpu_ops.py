@@ -231,6 +231,9 @@ F16S_CASES = [c for c in CONV_CASES if (c[6], c[7]) in ((3, 3), (1, 1))] + [
     (1, 3072, 0, 1024, 1, 256, 1, 1, 1, (0, 0)), # FFN down projection
     (2, 32, 0, 50, 70, 4, 1, 1, 1, (0, 0)),      # seg head, ragged spatial
     (1, 81, 0, 64, 64, 64, 3, 3, 1, (1, 1)),     # cost-volume encoder, Cin = 81
+    (2, 16, 8, 24, 40, 24, 3, 3, 1, (1, 1)),     # cat with ragged second input (C2 = 8 < chunk)
+    (2, 32, 40, 16, 16, 48, 1, 1, 1, (0, 0)),    # 1x1 on cat, ragged second input
+    (1, 6, 0, 33, 45, 70, 3, 3, 2, (1, 1)),      # stride 2, odd sizes, Cin < chunk, last sample's channel tail
 ]
 
 
@@ -243,6 +246,12 @@ def test_conv2d_f16s(dev, case):
     x2 = randn(B, C2, H, W, seed=31) if C2 else None
     w = randn(Cout, C1 + C2, kh, kw, seed=32) / math.sqrt((C1 + C2) * kh * kw)
     b = randn(Cout, seed=33)
+    if not ops.f16s_dynamic_ok(x1, x2, kh):
+        # a channel chunk would straddle cat[x1,x2]: the library must refuse (the module layer then uses the fp32 kernel)
+        wpk, ws = ops.pack_conv_weight_f16s(w.to(dev))
+        with pytest.raises(Exception):
+            ops.conv2d_f16s(x1.to(dev), wpk, ws, b.to(dev), Cout, kh, kw, stride, pad, x2=x2.to(dev))
+        return
     xin = x1 if x2 is None else torch.cat([x1, x2], 1)
     ref = F.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding=pad)
     wpk, ws = ops.pack_conv_weight_f16s(w.to(dev))

@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks on the shapes of the BASELINE workload (B = slices per step).
+Usage: python tools/microbench.py [--batch 16] [--only conv|gn|corr|attn|warp]"""
+import argparse
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cardiac-segmentation-optical-flow_amd"))
+import torch  # noqa: E402
+from cineflow import ops  # noqa: E402
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    B = args.batch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(0)
+
+    if args.only in ("", "conv"):
+        print("== conv (algorithmic TFLOP/s): f16s split vs exact fp32 MFMA")
+        cases = [  # C1, C2, H, Cout, k, stride
+            (6, 0, 256, 64, 3, 1), (64, 0, 256, 64, 3, 1), (64, 0, 256, 128, 3, 2), (128, 0, 128, 128, 3, 1), (128, 0, 128, 256, 3, 2),
+            (256, 0, 64, 256, 3, 1), (256, 0, 64, 256, 3, 2), (256, 0, 32, 256, 3, 1), (256, 256, 32, 512, 3, 1), (256, 256, 32, 256, 3, 1),
+            (64, 64, 256, 64, 3, 1), (128, 128, 128, 128, 3, 1), (64, 0, 256, 2, 3, 1), (81, 0, 256, 64, 3, 1),
+            (256, 0, 32, 768, 1, 1), (256, 0, 32, 2048, 1, 1), (2048, 0, 32, 256, 1, 1), (64, 0, 256, 64, 1, 1),
+            (32, 0, 256, 32, 3, 1), (480, 0, 16, 480, 3, 1), (480, 0, 8, 480, 3, 1),
+        ]
+        for (C1, C2, H, Cout, k, stride) in cases:
+            Bc = B * 4 if H <= 16 else B
+            x1 = torch.randn(Bc, C1, H, H, generator=g).to(dev)
+            x2 = torch.randn(Bc, C2, H, H, generator=g).to(dev) if C2 else None
+            w = (torch.randn(Cout, C1 + C2, k, k, generator=g) / math.sqrt((C1 + C2) * k * k)).to(dev)
+            wt = ops.prep_conv_weight(w)
+            wpk, ws = ops.pack_conv_weight_f16s(w)
+            pad = (k // 2, k // 2)
+            Ho = (H + 2 * pad[0] - k) // stride + 1
+            out = torch.empty(Bc, Cout, Ho, Ho, device=dev)
+            flops = 2.0 * Bc * Ho * Ho * Cout * (C1 + C2) * k * k
+            t16 = timeit(lambda: ops.conv2d_f16s(x1, wpk, ws, None, Cout, k, k, stride, pad, x2=x2, out=out))
+            t32 = timeit(lambda: ops.conv2d(x1, wt, None, Cout, k, k, stride, pad, x2=x2, out=out), iters=3, warm=1)
+            byts = 4.0 * (x1.numel() + (x2.numel() if C2 else 0) + out.numel())
+            print("  B%3d C%4d+%-3d %3dx%-3d -> %4d k%d s%d | f16s %8.1f us %7.1f TF (%5.0f GB/s) | fp32 %9.1f us %6.1f TF" %
+                  (Bc, C1, C2, H, H, Cout, k, stride, t16 * 1e6, flops / t16 / 1e12, byts / t16 / 1e9, t32 * 1e6, flops / t32 / 1e12))
+
+    if args.only in ("", "gn"):
+        print("== group norm (+GELU), bytes = read x (stats) + read x + write y")
+        for (C, H, groups) in [(64, 256, 8), (128, 128, 8), (256, 64, 8), (256, 32, 8), (32, 256, 32), (480, 8, 480)]:
+            x = torch.randn(B, C, H, H, generator=g).to(dev)
+            gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+            y = torch.empty_like(x)
+            t = timeit(lambda: ops.group_norm(x, gam, bet, groups, act="gelu", out=y))
+            print("  B%3d C%4d %3dx%-3d groups %3d: %8.1f us  %6.0f GB/s" % (B, C, H, H, groups, t * 1e6, 12.0 * x.numel() / t / 1e9))
+
+    if args.only in ("", "corr"):
+        print("== CorrVolume r=4 (algorithmic bytes: read cur+prev once, write 81 channels)")
+        for (C, H, s) in [(64, 256, 4), (128, 128, 2), (256, 64, 1)]:
+            a, b = torch.randn(B, C, H, H, generator=g).to(dev), torch.randn(B, C, H, H, generator=g).to(dev)
+            t = timeit(lambda: ops.corr_volume(a, b, 4, s))
+            byts = 4.0 * B * H * H * (2 * C + 81)
+            fl = 2.0 * 81 * C * H * H * B
+            print("  B%3d C%4d %3dx%-3d stride %d: %8.1f us  %6.0f GB/s  %6.2f TFLOP/s" % (B, C, H, H, s, t * 1e6, byts / t / 1e9, fl / t / 1e12))
+
+    if args.only in ("", "attn"):
+        print("== attention (N=1024, 4 heads x 64)")
+        q = torch.randn(B, 256, 1024, generator=g).to(dev)
+        t = timeit(lambda: ops.attention_cf(q, q, q, 4))
+        print("  B%3d: %8.1f us  %6.2f TFLOP/s" % (B, t * 1e6, 4.0 * B * 4 * 1024 * 1024 * 64 / t / 1e12))
+        x = torch.randn(B, 256, 1024, generator=g).to(dev)
+        gam, bet = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+        t = timeit(lambda: ops.layer_norm_cf(x, gam, bet))
+        print("  layer_norm_cf B%3d: %8.1f us  %6.0f GB/s" % (B, t * 1e6, 8.0 * x.numel() / t / 1e9))
+
+    if args.only in ("", "warp"):
+        print("== warp family (algorithmic bytes)")
+        flow = (3 * torch.randn(B, 2, 256, 256, generator=g)).to(dev)
+        for C in (1, 4):
+            src = torch.randn(B, C, 256, 256, generator=g).to(dev)
+            t = timeit(lambda: ops.warp_bilinear(flow, src))
+            print("  warp C=%d B%3d: %8.1f us  %6.0f GB/s" % (C, B, t * 1e6, 4.0 * B * 65536 * (2 + 2 * C) / t / 1e9))
+        lab = (torch.rand(B, 256, 256, generator=g) * 4).to(torch.uint8).to(dev)
+        fl = flow[None].contiguous()
+        t = timeit(lambda: ops.warp_labels(fl, lab))
+        print("  warp_labels B%3d: %8.1f us  %6.0f GB/s" % (B, t * 1e6, B * 65536 * (8 + 1 + 1) / t / 1e9))
+        t = timeit(lambda: ops.jacobian_det(flow))
+        print("  jacobian B%3d: %8.1f us  %6.0f GB/s" % (B, t * 1e6, B * 65536 * (8 + 8) / t / 1e9))
+
+
+if __name__ == "__main__":
+    main()

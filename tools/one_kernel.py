@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Run ONE kernel a few times (for rocprofv3 --pmc runs).  python tools/one_kernel.py conv 64 0 256 64 3 1 16"""
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cardiac-segmentation-optical-flow_amd"))
+import torch  # noqa: E402
+from cineflow import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+kind = sys.argv[1]
+g = torch.Generator().manual_seed(0)
+if kind == "conv":
+    C1, C2, H, Cout, k, stride, B = (int(v) for v in sys.argv[2:9])
+    x1 = torch.randn(B, C1, H, H, generator=g).to(dev)
+    x2 = torch.randn(B, C2, H, H, generator=g).to(dev) if C2 else None
+    w = (torch.randn(Cout, C1 + C2, k, k, generator=g) / math.sqrt((C1 + C2) * k * k)).to(dev)
+    wpk, ws = ops.pack_conv_weight_f16s(w)
+    for _ in range(5):
+        ops.conv2d_f16s(x1, wpk, ws, None, Cout, k, k, stride, (k // 2, k // 2), x2=x2)
+elif kind == "corr":
+    C, H, s, B = (int(v) for v in sys.argv[2:6])
+    a, b = torch.randn(B, C, H, H, generator=g).to(dev), torch.randn(B, C, H, H, generator=g).to(dev)
+    for _ in range(5):
+        ops.corr_volume(a, b, 4, s)
+elif kind == "gn":
+    C, H, groups, B = (int(v) for v in sys.argv[2:6])
+    x = torch.randn(B, C, H, H, generator=g).to(dev)
+    gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    for _ in range(5):
+        ops.group_norm(x, gam, bet, groups, act="gelu", inplace=False) if False else ops.group_norm(x, gam, bet, groups, act="gelu", out=torch.empty_like(x))
+torch.cuda.synchronize()
