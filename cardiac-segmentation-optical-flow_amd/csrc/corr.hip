@@ -18,21 +18,27 @@ namespace cf {
 //   * 9 dy x 32 (row,octet) = 288 threads (5 waves, last half-wave idle in the FMA loop, all 320 threads stage).
 // Global reads are full contiguous row segments (coalesced); writes of one wave cover whole 256-B row segments.
 // =====================================================================================================================
-constexpr int CV_CC = 8;        // channels per LDS chunk
-constexpr int CV_THREADS = 320;
+constexpr int CV_CC = 4;        // channels per LDS chunk
+constexpr int CV_THREADS = 512; // waves 0-4: compute (288 lanes used), waves 5-7: staging
+constexpr int CV_STAGERS = 192;
+constexpr int CV_MAXT = 2;      // float4 staging tasks per staging thread (12*(64+8S)/4 + 64 groups <= 2*192 for S in {1,2,4})
 
 template <int S>
-__global__ void __launch_bounds__(CV_THREADS) corr_volume_r4_kernel(const float* __restrict__ cur, const float* __restrict__ prev,
+__global__ void __launch_bounds__(CV_THREADS, 4) corr_volume_r4_kernel(const float* __restrict__ cur, const float* __restrict__ prev,
                                                                    float* __restrict__ out, int B, int C, int H, int W,
                                                                    int tiles_x, int tiles_y) {
     constexpr int NI = 64 / S;        // same-class pixels per tile row
     constexpr int PW = NI + 8;        // prev sub-row length (halo 4 each side)
-    constexpr int PROW = S * PW;      // floats per (c, prev row)
+    constexpr int PROW = S * PW;      // floats per (c, prev row) == real columns staged per row
     constexpr int CROW = 64;          // floats per (c, cur row)
     constexpr int PREV_C = 12 * PROW; // per channel
     constexpr int CUR_C = 4 * CROW;
-    __shared__ __attribute__((aligned(16))) float lds_prev[CV_CC * PREV_C];
-    __shared__ __attribute__((aligned(16))) float lds_cur[CV_CC * CUR_C];
+    constexpr int SLAB = PREV_C + CUR_C;        // floats per channel: [prev | cur]
+    constexpr int BUF = CV_CC * SLAB;           // floats per buffer
+    constexpr int PGRP = PROW / 4;              // float4 groups per prev row
+    constexpr int NGRP = 12 * PGRP + 4 * 16;    // staging groups per channel
+    static_assert(NGRP <= CV_MAXT * CV_STAGERS, "staging tasks");
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
     // ---- tile decode; blocks sharing an XCD (bid % 8) take a contiguous band of the tile list
     const int nb = gridDim.x;
@@ -49,12 +55,119 @@ __global__ void __launch_bounds__(CV_THREADS) corr_volume_r4_kernel(const float*
     const int b = t / tiles_y;
     const int xtile = tx * 64;
     const int ytile = ty * 4 * S;
-    const long HW = (long)H * W;
-    const float* curb = cur + (long)b * C * HW;
-    const float* prevb = prev + (long)b * C * HW;
+    const int HW = H * W;
+    const unsigned HW4 = (unsigned)HW * 4u;
 
-    // ---- compute-thread decode
+    // ---- staging tasks: one float4 (4 consecutive real x) of one tile row, for each of the CV_CC channels of a chunk.
+    // Raw buffer loads: rows / columns outside the image park the offset at 2 GiB, channels >= C run past num_records
+    // (the descriptor covers exactly this sample's C planes) -> the range check returns 0, no branches, no masks.
+    constexpr unsigned OOB = 0x80000000u;
     const int tid = threadIdx.x;
+    const bool stager = tid >= 320;   // wave-uniform role split: staging registers never live in the FMA waves
+    const int st = tid - 320;
+    unsigned t_off[CV_MAXT];   // byte offset inside the sample (channel 0)
+    int t_lds[CV_MAXT];        // float index inside a channel slab of the first of the 4 elements, -1: no task
+    bool t_prev[CV_MAXT];
+#pragma unroll
+    for (int k = 0; k < CV_MAXT; ++k) {
+        const int grp = stager ? st + k * CV_STAGERS : NGRP;
+        t_off[k] = OOB;
+        t_lds[k] = -1;
+        t_prev[k] = true;
+        if (grp < 12 * PGRP) {
+            const int pr = grp / PGRP, col = (grp - pr * PGRP) * 4;   // real column offset inside the staged row
+            const int y = ytile + S * (pr - 4) + ry, x = xtile - 4 * S + col;
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) t_off[k] = (unsigned)(y * W + x) * 4u;
+            // de-interleave by x class: element e (0..3) of the float4 has class (col+e)%S and index (col+e)/S
+            t_lds[k] = pr * PROW + (col % S) * PW + col / S;
+        } else if (grp < NGRP) {
+            const int g2 = grp - 12 * PGRP;
+            const int rr = g2 >> 4, col = (g2 & 15) * 4;
+            const int y = ytile + S * rr + ry, x = xtile + col;
+            if (y < H && x < W) t_off[k] = (unsigned)(y * W + x) * 4u;
+            t_lds[k] = PREV_C + rr * CROW + (col % S) * NI + col / S;
+            t_prev[k] = false;
+        }
+    }
+    const long sample = (long)b * C * HW;
+    const __amdgpu_buffer_rsrc_t rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(prev + sample), 0, (int)((long)C * HW4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cur + sample), 0, (int)((long)C * HW4), 0x00020000);
+
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int nchunk = (C + CV_CC - 1) / CV_CC;
+    if (stager) {
+        // ---- staging waves.  Two register sets (A, B) keep the loads of TWO chunks in flight, so the wait in front of
+        // each LDS write is for loads issued a whole chunk period earlier (vmcnt retires in order: waiting for the older
+        // set leaves the younger one in flight).  The loop is unrolled by two so that the sets are statically indexed.
+        // Same number of barriers as the FMA branch (1 + nchunk).
+        f32x4 sa[CV_MAXT][CV_CC], sb[CV_MAXT][CV_CC];
+        auto issue_loads = [&](int ch, f32x4 (&stg)[CV_MAXT][CV_CC]) {
+            const int c0 = ch * CV_CC;
+#pragma unroll
+            for (int k = 0; k < CV_MAXT; ++k)
+#pragma unroll
+                for (int c = 0; c < CV_CC; ++c) {
+                    const unsigned off = t_off[k] + (unsigned)(c0 + c) * HW4;
+                    stg[k][c] = t_prev[k] ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_prev, off, 0, 0))
+                                          : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cur, off, 0, 0));
+                }
+        };
+        auto write_stage = [&](int ch, const f32x4 (&stg)[CV_MAXT][CV_CC]) {
+            float* base = lds + (ch & 1) * BUF;
+#pragma unroll
+            for (int k = 0; k < CV_MAXT; ++k) {
+                if (t_lds[k] < 0) continue;
+                const int cls_stride = t_prev[k] ? PW : NI;
+#pragma unroll
+                for (int c = 0; c < CV_CC; ++c) {
+                    float* d = base + c * SLAB + t_lds[k];
+                    if (S == 1) {
+                        *reinterpret_cast<f32x4*>(d) = stg[k][c];
+                    } else if (S == 2) {  // classes 0,1,0,1 : elements (0,2) and (1,3) are neighbours inside their class rows
+                        d[0] = stg[k][c][0]; d[1] = stg[k][c][2];
+                        d[cls_stride] = stg[k][c][1]; d[cls_stride + 1] = stg[k][c][3];
+                    } else {              // S == 4: one element per class
+                        d[0] = stg[k][c][0]; d[cls_stride] = stg[k][c][1]; d[2 * cls_stride] = stg[k][c][2]; d[3 * cls_stride] = stg[k][c][3];
+                    }
+                }
+            }
+        };
+        if (S == 4) {
+            // the scalar de-interleaving LDS writes of the stride-4 variant need the registers of the second set:
+            // one chunk in flight only (no spill at 128 VGPRs)
+            issue_loads(0, sa);
+            write_stage(0, sa);
+            __syncthreads();
+            for (int ch = 0; ch < nchunk; ++ch) {
+                if (ch + 1 < nchunk) {
+                    issue_loads(ch + 1, sa);
+                    write_stage(ch + 1, sa);
+                }
+                __syncthreads();
+            }
+            return;
+        }
+        issue_loads(0, sa);
+        if (nchunk > 1) issue_loads(1, sb);
+        write_stage(0, sa);
+        __syncthreads();
+        int ch = 0;
+        while (true) {
+            // chunk ch is in LDS; set B holds chunk ch+1 (in flight); set A is free
+            if (ch + 2 < nchunk) issue_loads(ch + 2, sa);
+            if (ch + 1 < nchunk) write_stage(ch + 1, sb);
+            __syncthreads();
+            if (++ch >= nchunk) break;
+            // chunk ch is in LDS; set A holds chunk ch+1; set B is free
+            if (ch + 2 < nchunk) issue_loads(ch + 2, sb);
+            if (ch + 1 < nchunk) write_stage(ch + 1, sa);
+            __syncthreads();
+            if (++ch >= nchunk) break;
+        }
+        return;
+    }
+
+    // ---- FMA waves (the roles live in separate loops so that staging registers and accumulators never coexist)
     const bool compute = tid < 288;
     const int dy = tid >> 5;          // 0..8  (displacement dy-4)
     const int qd = tid & 31;
@@ -62,8 +175,8 @@ __global__ void __launch_bounds__(CV_THREADS) corr_volume_r4_kernel(const float*
     const int u = qd & 7;
     const int rx = u % S;             // x residue class
     const int o = u / S;              // octet within the class row
-    const int prev_off = ((r + dy) * S + rx) * PW + 8 * o;   // + c*PREV_C ; window [8o, 8o+16)
-    const int cur_off = r * CROW + rx * NI + 8 * o;          // + c*CUR_C
+    const int prev_off = ((r + dy) * S + rx) * PW + 8 * o;       // + c*SLAB ; window [8o, 8o+16)
+    const int cur_off = PREV_C + r * CROW + rx * NI + 8 * o;     // + c*SLAB
 
     float acc[8][9];
 #pragma unroll
@@ -71,36 +184,14 @@ __global__ void __launch_bounds__(CV_THREADS) corr_volume_r4_kernel(const float*
 #pragma unroll
         for (int d = 0; d < 9; ++d) acc[j][d] = 0.f;
 
-    for (int c0 = 0; c0 < C; c0 += CV_CC) {
-        __syncthreads();
-        // stage prev: CV_CC x 12 rows x (64 + 8S) real columns, coalesced along x, de-interleaved on the LDS side
-        constexpr int PCOLS = 64 + 8 * S;
-        for (int e = tid; e < CV_CC * 12 * PCOLS; e += CV_THREADS) {
-            int col = e % PCOLS;
-            int rest = e / PCOLS;
-            int pr = rest % 12, c = rest / 12;
-            int y = ytile + S * (pr - 4) + ry;
-            int x = xtile - 4 * S + col;
-            float val = 0.f;
-            if (c0 + c < C && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) val = prevb[(long)(c0 + c) * HW + (long)y * W + x];
-            lds_prev[c * PREV_C + (pr * S + (col % S)) * PW + col / S] = val;
-        }
-        for (int e = tid; e < CV_CC * 4 * 64; e += CV_THREADS) {
-            int col = e & 63;
-            int rest = e >> 6;
-            int rr = rest & 3, c = rest >> 2;
-            int y = ytile + S * rr + ry;
-            int x = xtile + col;
-            float val = 0.f;
-            if (c0 + c < C && y < H && x < W) val = curb[(long)(c0 + c) * HW + (long)y * W + x];
-            lds_cur[c * CUR_C + rr * CROW + (col % S) * NI + col / S] = val;
-        }
-        __syncthreads();
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
         if (compute) {
-#pragma unroll 2
+            const float* xb = lds + (ch & 1) * BUF;
+#pragma unroll
             for (int c = 0; c < CV_CC; ++c) {
-                const float4* pp = reinterpret_cast<const float4*>(&lds_prev[c * PREV_C + prev_off]);
-                const float4* cp = reinterpret_cast<const float4*>(&lds_cur[c * CUR_C + cur_off]);
+                const float4* pp = reinterpret_cast<const float4*>(xb + c * SLAB + prev_off);
+                const float4* cp = reinterpret_cast<const float4*>(xb + c * SLAB + cur_off);
                 float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
                 float4 c0v = cp[0], c1v = cp[1];
                 const float pv[16] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w, p3.x, p3.y, p3.z, p3.w};
@@ -111,6 +202,7 @@ __global__ void __launch_bounds__(CV_THREADS) corr_volume_r4_kernel(const float*
                     for (int d = 0; d < 9; ++d) acc[j][d] = fmaf(cv[j], pv[j + d], acc[j][d]);
             }
         }
+        __syncthreads();
     }
     if (!compute) return;
     const int y = ytile + S * r + ry;
@@ -245,7 +337,8 @@ extern "C" int cf_corr_volume(const float* cur, const float* prev, float* out, i
     CF_REQUIRE(cur && prev && out, "null pointer");
     CF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && radius >= 0 && radius <= 8 && stride >= 1, "bad shape");
     hipStream_t s = as_stream(stream);
-    if (radius == 4 && (stride == 1 || stride == 2 || stride == 4)) {
+    if (radius == 4 && (stride == 1 || stride == 2 || stride == 4) && (W & 3) == 0 && (long)C * H * W * 4 < (1L << 31) &&
+        ((reinterpret_cast<uintptr_t>(cur) | reinterpret_cast<uintptr_t>(prev)) & 15) == 0) {
         int tiles_x = (W + 63) / 64, tiles_y = (H + 4 * stride - 1) / (4 * stride);
         long nblk = (long)B * tiles_y * stride * tiles_x;
         CF_REQUIRE(nblk < (1L << 31), "grid too large");
