@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .nn import (Module, Conv2d, ConvTranspose2d, GroupNorm, ConvBlocks2DGroupLegacy, Encoder2D, Decoder2D, CrossAttentionLayer,
+from .nn import (Module, conv_norm, Conv2d, ConvTranspose2d, GroupNorm, ConvBlocks2DGroupLegacy, Encoder2D, Decoder2D, CrossAttentionLayer,
                  TransformerFlowEncoderSuccessiveNoEmb, ConvGRUCell, SpatialTransformer, VecInt)
 
 
@@ -373,7 +373,7 @@ class ConvDropoutNormNonlin(Module):
         self.instnorm = GroupNorm(cout, cout)
 
     def forward(self, x, x2=None):
-        return self.instnorm(self.conv(x, x2=x2), act="lrelu")
+        return conv_norm(self.conv, self.instnorm, x, x2=x2, act="lrelu")
 
 
 class StackedConvLayers(Module):

@@ -91,10 +91,14 @@ class Conv2d(Module):
             if self._f16s:
                 self._wpk, self._ws = ops.pack_conv_weight_f16s(self._p["weight"])
 
-    def forward(self, x, x2=None, act=None, res=None, out=None, out_coff=0):
+    def forward(self, x, x2=None, act=None, res=None, out=None, out_coff=0, stats_groups=None):
+        """stats_groups=G: returns (out, ws) with the GroupNorm statistics of `out` when the f16 kernel can fuse them, else (out, None)."""
         if self._f16s and ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, x2, self.ks[0]):
             return ops.conv2d_f16s(x, self._wpk, self._ws, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad,
-                                   x2=x2, act=act, res=res, out=out, out_coff=out_coff)
+                                   x2=x2, act=act, res=res, out=out, out_coff=out_coff, stats_groups=stats_groups)
+        if stats_groups:
+            return ops.conv2d(x, self._wt, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad, x2=x2, act=act,
+                              res=res, out=out, out_coff=out_coff), None
         return ops.conv2d(x, self._wt, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad, x2=x2, act=act,
                           res=res, out=out, out_coff=out_coff)
 
@@ -114,10 +118,12 @@ class ConvTranspose2d(Module):
             w = self._p["weight"]  # [Cin,Cout,2,2] -> GEMM rows m = co*4 + dy*2 + dx
             self._wpk, self._ws = ops.pack_conv_weight_f16s(w.permute(1, 2, 3, 0).reshape(self.cout * 4, self.cin, 1, 1))
 
-    def forward(self, x, out=None, out_coff=0):
+    def forward(self, x, out=None, out_coff=0, stats_groups=None):
         if ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, None, 1):
-            return ops.conv_transpose2d_k2s2_f16s(x, self._wpk, self._ws, self._p.get("bias"), self.cout, out=out, out_coff=out_coff)
-        return ops.conv_transpose2d_k2s2(x, self._p["weight"], self._p.get("bias"), out=out, out_coff=out_coff)
+            return ops.conv_transpose2d_k2s2_f16s(x, self._wpk, self._ws, self._p.get("bias"), self.cout, out=out, out_coff=out_coff,
+                                                  stats_groups=stats_groups)
+        y = ops.conv_transpose2d_k2s2(x, self._p["weight"], self._p.get("bias"), out=out, out_coff=out_coff)
+        return (y, None) if stats_groups else y
 
 
 class GroupNorm(Module):
@@ -130,9 +136,20 @@ class GroupNorm(Module):
         self._param("weight", (channels,))
         self._param("bias", (channels,))
 
-    def forward(self, x, act=None, res=None, res_mode=None, inplace=True):
+    def forward(self, x, act=None, res=None, res_mode=None, inplace=True, ws=None):
+        """ws: statistics already accumulated by the producing convolution's epilogue -> apply pass only."""
+        if ws is not None:
+            return ops.group_norm_apply(x, self._p["weight"], self._p["bias"], self.groups, ws, self.eps, act=act, res=res,
+                                        res_mode=res_mode, out=x if inplace else None)
         return ops.group_norm(x, self._p["weight"], self._p["bias"], self.groups, self.eps, act=act, res=res, res_mode=res_mode,
                               out=x if inplace else None)
+
+
+def conv_norm(conv, norm, x, x2=None, act=None, res=None, res_mode=None):
+    """norm(conv(x)) with the GroupNorm statistics accumulated in the convolution's epilogue when possible."""
+    kw = {} if x2 is None else {"x2": x2}
+    y, ws = conv(x, stats_groups=norm.groups, **kw)
+    return norm(y, act=act, res=res, res_mode=res_mode, ws=ws)
 
 
 class LayerNormCF(Module):
@@ -165,16 +182,15 @@ class DoubleConv(Module):
             self.downsample = {0: Conv2d(in_dim, out_dim, 1, stride=stride), 1: GroupNorm(8, out_dim)}
 
     def forward(self, x, x2=None):
-        t = self.norm1(self.conv1(x, x2=x2), act="gelu")
-        t = self.conv2(t)
+        t = conv_norm(self.conv1, self.norm1, x, x2=x2, act="gelu")
         if not self.residual:
-            return self.norm2(t, act="gelu")
+            return conv_norm(self.conv2, self.norm2, t, act="gelu")
         if self.has_ds:
-            r = self.downsample[1](self.downsample[0](x, x2=x2))
+            r = conv_norm(self.downsample[0], self.downsample[1], x, x2=x2)
         else:
             assert x2 is None
             r = x
-        return self.norm2(t, act="gelu", res=r, res_mode="after_act")
+        return conv_norm(self.conv2, self.norm2, t, act="gelu", res=r, res_mode="after_act")
 
 
 class SingleConv(Module):
@@ -190,11 +206,10 @@ class SingleConv(Module):
             self.downsample = Conv2d(in_dim, out_dim, 1, stride=stride)
 
     def forward(self, x, x2=None):
-        t = self.conv1(x, x2=x2)
         if not self.residual:
-            return self.norm1(t, act="gelu")
+            return conv_norm(self.conv1, self.norm1, x, x2=x2, act="gelu")
         r = self.downsample(x, x2=x2) if self.has_ds else x
-        return self.norm1(t, act="gelu", res=r, res_mode="before_act")
+        return conv_norm(self.conv1, self.norm1, x, x2=x2, act="gelu", res=r, res_mode="before_act")
 
 
 class ConvBlocks2DGroupLegacy(Module):
@@ -221,7 +236,7 @@ class PatchExpand2DGroup(Module):
         self.up = {0: ConvTranspose2d(in_dim, out_dim), 1: GroupNorm(8, out_dim)}
 
     def forward(self, x):
-        return self.up[1](self.up[0](x), act="gelu")
+        return conv_norm(self.up[0], self.up[1], x, act="gelu")
 
 
 class PatchMerging2DGroup(Module):
@@ -232,7 +247,7 @@ class PatchMerging2DGroup(Module):
         self.reduction = {0: Conv2d(in_dim, out_dim, 3, stride=2, padding=1), 1: GroupNorm(8, out_dim)}
 
     def forward(self, x):
-        return self.reduction[1](self.reduction[0](x), act="gelu")
+        return conv_norm(self.reduction[0], self.reduction[1], x, act="gelu")
 
 
 # --------------------------------------------------------------------------------------------- encoder / decoder

@@ -177,7 +177,9 @@ def pack_conv_weight_f16s(w):
     return x.view(-1), s
 
 
-def conv2d_f16s(x1, wpk, wscale, bias, cout, kh, kw, stride=1, pad=(0, 0), x2=None, act=None, res=None, out=None, out_coff=0, alpha=1.0):
+def conv2d_f16s(x1, wpk, wscale, bias, cout, kh, kw, stride=1, pad=(0, 0), x2=None, act=None, res=None, out=None, out_coff=0, alpha=1.0,
+                stats_groups=None):
+    """With stats_groups=G the call returns (out, ws): ws holds the GroupNorm statistics of `out` for group_norm_apply."""
     B, C1, H, W = x1.shape
     C2 = 0 if x2 is None else x2.shape[1]
     Ho = (H + 2 * pad[0] - kh) // stride + 1
@@ -188,18 +190,22 @@ def conv2d_f16s(x1, wpk, wscale, bias, cout, kh, kw, stride=1, pad=(0, 0), x2=No
     if res is not None:
         assert res.shape == (B, cout, Ho, Wo)
     assert wpk.dtype == torch.float16 and wpk.is_cuda
+    ws = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x1.device) if stats_groups else None
     check(lib().cf_conv2d_f16s(_f32(x1), C1, _opt(x2), C2, wpk.data_ptr(), _opt(bias), _opt(res), _f32(out), out.shape[1], out_coff, B, H, W,
-                               cout, kh, kw, stride, pad[0], pad[1], ACT[act], float(alpha) * (2.0 ** -wscale), _stream()), "cf_conv2d_f16s")
-    return out
+                               cout, kh, kw, stride, pad[0], pad[1], ACT[act], float(alpha) * (2.0 ** -wscale),
+                               None if ws is None else ws.data_ptr(), stats_groups or 0, _stream()), "cf_conv2d_f16s")
+    return (out, ws) if stats_groups else out
 
 
-def conv_transpose2d_k2s2_f16s(x, wpk, wscale, bias, cout, out=None, out_coff=0):
+def conv_transpose2d_k2s2_f16s(x, wpk, wscale, bias, cout, out=None, out_coff=0, stats_groups=None):
     B, Cin, H, W = x.shape
     if out is None:
         out = torch.empty((B, cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
     check(lib().cf_conv_transpose2d_k2s2_f16s(_f32(x), wpk.data_ptr(), _opt(bias), _f32(out), out.shape[1], out_coff, B, Cin, H, W, cout,
-                                              2.0 ** -wscale, _stream()), "cf_conv_transpose2d_k2s2_f16s")
-    return out
+                                              2.0 ** -wscale, None if ws is None else ws.data_ptr(), stats_groups or 0, _stream()),
+          "cf_conv_transpose2d_k2s2_f16s")
+    return (out, ws) if stats_groups else out
 
 
 def conv2d(x1, wt, bias, cout, kh, kw, stride=1, pad=(0, 0), x2=None, act=None, res=None, out=None, out_coff=0, alpha=1.0,
@@ -254,6 +260,18 @@ def group_norm(x, gamma, beta, groups, eps=1e-5, act=None, res=None, res_mode=No
     ws = _stats_ws(2 * B * groups, x.device)
     check(lib().cf_group_norm(_f32(x), _opt(gamma), _opt(beta), _opt(res), _f32(out), B, C, HW, groups, float(eps), ACT[act],
                               RES[res_mode if res is not None else None], ws.data_ptr(), _stream()), "cf_group_norm")
+    return out
+
+
+def group_norm_apply(x, gamma, beta, groups, ws, eps=1e-5, act=None, res=None, res_mode=None, out=None):
+    """Apply pass only; `ws` from conv2d_f16s(..., stats_groups=groups)."""
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    if out is None:
+        out = torch.empty_like(x)
+    assert ws.dtype == torch.float64 and ws.numel() >= 2 * B * groups
+    check(lib().cf_group_norm_apply(_f32(x), _opt(gamma), _opt(beta), _opt(res), _f32(out), B, C, HW, groups, float(eps), ACT[act],
+                                    RES[res_mode if res is not None else None], ws.data_ptr(), _stream()), "cf_group_norm_apply")
     return out
 
 

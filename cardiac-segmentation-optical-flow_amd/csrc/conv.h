@@ -18,6 +18,8 @@ struct ConvParams {
     int act;
     float alpha;
     int scatter2x2;       // 1: ConvTranspose k2s2 epilogue (GEMM row m = co*4 + dy*2 + dx)
+    double* gn_ws;        // optional: accumulate GroupNorm statistics of the OUTPUT (sum, sum of squares per (sample, group))
+    int gn_groups;
 };
 
 // validates nothing; callers validate.  Returns CF_OK / CF_ERR_LAUNCH.
@@ -26,5 +28,8 @@ int launch_conv(const ConvParams& p, hipStream_t s);
 // f16 hi/lo-split kernel (conv_f16s.hip)
 bool conv_f16s_supported(const ConvParams& p);
 int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s);
+
+// GroupNorm statistics pass (norm.hip): ws[2*(b*groups+g)] = sum, +1 = sum of squares, fp64
+int launch_gn_stats(const float* x, double* ws, int B, int C, int HW, int groups, hipStream_t s);
 
 }  // namespace cf

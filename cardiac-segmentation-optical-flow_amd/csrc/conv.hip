@@ -217,7 +217,7 @@ extern "C" int cf_conv2d(const float* x1, int C1, const float* x2, int C2, const
     p.x1 = x1; p.x2 = C2 ? x2 : nullptr; p.wt = wt; p.bias = bias; p.res = res; p.out = out; p.w_bstride = w_bstride;
     p.C1 = C1; p.C2 = C2; p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;
     p.pad_h = pad_h; p.pad_w = pad_w; p.Ho = Ho; p.Wo = Wo; p.out_ctotal = out_ctotal; p.out_coff = out_coff; p.act = act;
-    p.alpha = alpha; p.scatter2x2 = 0;
+    p.alpha = alpha; p.scatter2x2 = 0; p.gn_ws = nullptr; p.gn_groups = 0;
     return launch_conv(p, as_stream(stream));
 }
 
@@ -231,6 +231,6 @@ extern "C" int cf_conv_transpose2d_k2s2(const float* x, const float* w, const fl
     p.x1 = x; p.x2 = nullptr; p.wt = w; p.bias = bias; p.res = nullptr; p.out = out; p.w_bstride = 0;
     p.C1 = Cin; p.C2 = 0; p.B = B; p.H = H; p.W = W; p.Cout = Cout * 4; p.KH = 1; p.KW = 1; p.stride = 1;
     p.pad_h = 0; p.pad_w = 0; p.Ho = H; p.Wo = W; p.out_ctotal = out_ctotal; p.out_coff = out_coff; p.act = CF_ACT_NONE;
-    p.alpha = 1.f; p.scatter2x2 = 1;
+    p.alpha = 1.f; p.scatter2x2 = 1; p.gn_ws = nullptr; p.gn_groups = 0;
     return launch_conv(p, as_stream(stream));
 }

@@ -246,6 +246,14 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
     }
 
     // ---- epilogue (same fusion as conv.hip): value = act(alpha*acc + bias) + res  (alpha carries the weight scale 2^-s)
+    // Optional fused GroupNorm / InstanceNorm statistics of the stored values (sum, sum of squares per (sample, group)):
+    // per lane the NTW tiles are added per register (= channel), then a transpose-reduce over the 32 pixel lanes of the
+    // half-wave (16 -> 8 -> 4 -> 2 -> 1 registers, 16 shuffles per quantity instead of 80) leaves each channel's total in
+    // one lane pair, which adds it to the fp64 workspace.  Host guarantees one sample per workgroup (NIMG == 1).
+    const bool do_stats = p.gn_ws != nullptr;
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -266,6 +274,67 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
             float v = act_apply(p.alpha * acc1[nt][r] + bv, p.act);
             if (p.res) v += p.res[r_off[nt] + (long)co * HoWo];
             p.out[o_off[nt] + ochan] = v;
+            ssum[r] += v;
+            ssq[r] += v * v;
+        }
+    }
+    if (do_stats) {
+        auto xreduce = [&](float (&v)[16]) {
+            // after this, lane bits (b4 b3 b2 b1) select register 8*b4 + 4*b3 + 2*b2 + b1, summed over the 32 lanes of the half
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const bool up = (lane & 16) != 0;
+                const float keep = up ? v[i + 8] : v[i], send = up ? v[i] : v[i + 8];
+                v[i] = keep + __shfl_xor(send, 16, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool up = (lane & 8) != 0;
+                const float keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
+                v[i] = keep + __shfl_xor(send, 8, 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool up = (lane & 4) != 0;
+                const float keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
+                v[i] = keep + __shfl_xor(send, 4, 64);
+            }
+            {
+                const bool up = (lane & 2) != 0;
+                const float keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+                v[0] = keep + __shfl_xor(send, 2, 64);
+            }
+            v[0] += __shfl_xor(v[0], 1, 64);
+        };
+        xreduce(ssum);
+        xreduce(ssq);
+        // workgroup-level combine in LDS (the staging buffers are free now), then ONE fp64 atomic pair per (group, workgroup):
+        // thousands of workgroups adding to the same 8 groups of a sample would otherwise serialise at the memory side.
+        float* red = reinterpret_cast<float*>(lds);  // [WM*32 channels][2]
+        __syncthreads();                              // every wave is done reading the last LDS buffer
+        if (tid < WM * 64) red[tid] = 0.f;
+        __syncthreads();
+        if ((lane & 1) == 0) {
+            const int r = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+            const int cl = (WM == 2 ? (wave & 1) * 32 : 0) + (r & 3) + 8 * (r >> 2) + 4 * half;  // channel inside the workgroup's block
+            atomicAdd(&red[2 * cl], ssum[0]);
+            atomicAdd(&red[2 * cl + 1], ssq[0]);
+        }
+        __syncthreads();
+        if (tid < WM * 32 && b0 < p.B) {
+            const int cb = blockIdx.y * WM * 32;
+            const int co = cb + tid;
+            const int cpg = p.Cout / p.gn_groups;
+            if (co < p.Cout && (tid == 0 || co % cpg == 0)) {
+                int n = cpg - co % cpg;               // channels of this group from co on
+                if (n > WM * 32 - tid) n = WM * 32 - tid;
+                if (n > p.Cout - co) n = p.Cout - co;
+                float s1 = 0.f, s2 = 0.f;
+                for (int j = 0; j < n; ++j) { s1 += red[2 * (tid + j)]; s2 += red[2 * (tid + j) + 1]; }
+                double* w = p.gn_ws + 2L * ((long)b0 * p.gn_groups + co / cpg);
+                atomicAdd(w, (double)s1);
+                atomicAdd(w + 1, (double)s2);
+            }
         }
     }
 }
@@ -325,7 +394,29 @@ static int f16s_small_tile() {
     return v;
 }
 
+static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipStream_t s, bool* one_sample_per_wg);
+
+// Runs the convolution; when p.gn_ws is set the workspace ends up holding the GroupNorm statistics of the output --
+// from the fused epilogue when every workgroup covers a single sample, otherwise from the separate statistics pass.
 int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
+    if (!p.gn_ws) return launch_conv_f16s_impl(p, wpk, s, nullptr);
+    bool fusable = false;
+    launch_conv_f16s_impl(p, nullptr, s, &fusable);  // geometry probe only
+    ConvParams q = p;
+    if (fusable && !p.scatter2x2) {
+        if (hipMemsetAsync(p.gn_ws, 0, sizeof(double) * 2 * (size_t)p.B * p.gn_groups, s) != hipSuccess) { set_error("conv_f16s: memset failed"); return CF_ERR_LAUNCH; }
+        return launch_conv_f16s_impl(q, wpk, s, nullptr);
+    }
+    q.gn_ws = nullptr;
+    int rc = launch_conv_f16s_impl(q, wpk, s, nullptr);
+    if (rc != CF_OK) return rc;
+    const int up = p.scatter2x2 ? 2 : 1;
+    const int cout = p.scatter2x2 ? p.Cout / 4 : p.Cout;
+    if (p.out_coff != 0 || p.out_ctotal != cout) { set_error("conv_f16s: GroupNorm statistics need a dense output tensor"); return CF_ERR_ARG; }
+    return launch_gn_stats(p.out, p.gn_ws, p.B, cout, p.Ho * up * p.Wo * up, p.gn_groups, s);
+}
+
+static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipStream_t s, bool* one_sample_per_wg) {
     const bool k3 = p.KH == 3;
     const int CK = k3 ? 16 : 32;
     const bool narrow = p.Cout <= 32;
@@ -365,6 +456,10 @@ int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
     g.tiles_y = (p.Ho + g.TH - 1) / g.TH;
     g.bgroups = (p.B + g.NIMG - 1) / g.NIMG;
     g.nchunk = (p.C1 + p.C2 + CK - 1) / CK;
+    if (one_sample_per_wg) {  // geometry probe
+        *one_sample_per_wg = g.NIMG == 1;
+        return CF_OK;
+    }
     if (small && s2) return launch_f16s<9, 16, 2, 1, 3>(p, g, wpk, s);
     if (small) return k3 ? launch_f16s<9, 16, 2, 2, 2>(p, g, wpk, s) : launch_f16s<1, 32, 2, 2, 2>(p, g, wpk, s);
     if (k3) {
@@ -380,7 +475,7 @@ using namespace cf;
 
 extern "C" int cf_conv2d_f16s(const float* x1, int C1, const float* x2, int C2, const void* wpk, const float* bias, const float* res,
                               float* out, int out_ctotal, int out_coff, int B, int H, int W, int Cout, int KH, int KW, int stride,
-                              int pad_h, int pad_w, int act, float alpha, void* stream) {
+                              int pad_h, int pad_w, int act, float alpha, double* gn_ws, int gn_groups, void* stream) {
     CF_REQUIRE(x1 && wpk && out, "null pointer");
     CF_REQUIRE(C1 > 0 && C2 >= 0 && (C2 == 0 || x2), "bad channel split C1=%d C2=%d", C1, C2);
     CF_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0, "bad shape B=%d H=%d W=%d Cout=%d", B, H, W, Cout);
@@ -392,13 +487,16 @@ extern "C" int cf_conv2d_f16s(const float* x1, int C1, const float* x2, int C2, 
     p.C1 = C1; p.C2 = C2; p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;
     p.pad_h = pad_h; p.pad_w = pad_w; p.Ho = (H + 2 * pad_h - KH) / stride + 1; p.Wo = (W + 2 * pad_w - KW) / stride + 1;
     p.out_ctotal = out_ctotal; p.out_coff = out_coff; p.act = act; p.alpha = alpha; p.scatter2x2 = 0;
+    p.gn_ws = gn_ws; p.gn_groups = gn_groups;
+    CF_REQUIRE(!gn_ws || (gn_groups > 0 && Cout % gn_groups == 0 && out_coff == 0 && out_ctotal == Cout), "bad GroupNorm statistics request");
     CF_REQUIRE(p.Ho > 0 && p.Wo > 0, "empty output");
     CF_REQUIRE(conv_f16s_supported(p), "unsupported configuration for the f16-split kernel (3x3 pad 1 or 1x1 pad 0, stride 1/2)");
     return launch_conv_f16s(p, reinterpret_cast<const _Float16*>(wpk), as_stream(stream));
 }
 
 extern "C" int cf_conv_transpose2d_k2s2_f16s(const float* x, const void* wpk, const float* bias, float* out, int out_ctotal,
-                                             int out_coff, int B, int Cin, int H, int W, int Cout, float alpha, void* stream) {
+                                             int out_coff, int B, int Cin, int H, int W, int Cout, float alpha, double* gn_ws, int gn_groups,
+                                             void* stream) {
     CF_REQUIRE(x && wpk && out, "null pointer");
     CF_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0, "bad shape");
     CF_REQUIRE(out_coff >= 0 && out_coff + Cout <= out_ctotal, "output channel slice out of range");
@@ -407,6 +505,7 @@ extern "C" int cf_conv_transpose2d_k2s2_f16s(const float* x, const void* wpk, co
     p.x1 = x; p.x2 = nullptr; p.wt = nullptr; p.bias = bias; p.res = nullptr; p.out = out; p.w_bstride = 0;
     p.C1 = Cin; p.C2 = 0; p.B = B; p.H = H; p.W = W; p.Cout = Cout * 4; p.KH = 1; p.KW = 1; p.stride = 1;
     p.pad_h = 0; p.pad_w = 0; p.Ho = H; p.Wo = W; p.out_ctotal = out_ctotal; p.out_coff = out_coff; p.act = CF_ACT_NONE;
-    p.alpha = alpha; p.scatter2x2 = 1;
+    p.alpha = alpha; p.scatter2x2 = 1; p.gn_ws = gn_ws; p.gn_groups = gn_groups;
+    CF_REQUIRE(!gn_ws || (gn_groups > 0 && Cout % gn_groups == 0 && out_coff == 0 && out_ctotal == Cout), "bad GroupNorm statistics request");
     return launch_conv_f16s(p, reinterpret_cast<const _Float16*>(wpk), as_stream(stream));
 }

@@ -369,7 +369,7 @@ extern "C" int cf_corr_pyramid(const float* f1, const float* f2, float* pyr, int
     p.x1 = f2; p.x2 = nullptr; p.wt = f1; p.bias = nullptr; p.res = nullptr; p.out = pyr; p.w_bstride = (long)C * N;
     p.C1 = C; p.C2 = 0; p.B = B; p.H = H; p.W = W; p.Cout = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad_h = 0; p.pad_w = 0;
     p.Ho = H; p.Wo = W; p.out_ctotal = N; p.out_coff = 0; p.act = CF_ACT_NONE; p.alpha = (float)(1.0 / sqrt((double)C));
-    p.scatter2x2 = 0;
+    p.scatter2x2 = 0; p.gn_ws = nullptr; p.gn_groups = 0;
     int rc = launch_conv(p, s);
     if (rc != CF_OK) return rc;
     long off = 0;

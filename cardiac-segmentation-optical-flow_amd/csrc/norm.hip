@@ -3,7 +3,7 @@
 // Statistics are accumulated in fp64 (sum, sum of squares): E[x^2]-E[x]^2 is then exact to ~1e-16 relative, so the
 // result matches PyTorch's two-pass/Welford CPU kernels to fp32 rounding.  In NCHW a (sample, group) slab is one
 // contiguous run of (C/groups)*HW floats, so the statistics pass is a plain segmented reduction.
-#include "common.h"
+#include "conv.h"
 
 namespace cf {
 
@@ -162,7 +162,28 @@ __global__ void __launch_bounds__(256) layer_norm_cf_kernel(const float* __restr
 
 }  // namespace cf
 
+namespace cf {
+int launch_gn_stats(const float* x, double* ws, int B, int C, int HW, int groups, hipStream_t s) {
+    const long nslabs = (long)B * groups;
+    const int L = (C / groups) * HW;
+    if (L <= 4096 || (L & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) {
+        hipLaunchKernelGGL(gn_stats_wave_kernel, dim3(cdiv(nslabs, 4)), dim3(256), 0, s, x, ws, nslabs, L);
+    } else {
+        if (hipMemsetAsync(ws, 0, sizeof(double) * 2 * nslabs, s) != hipSuccess) { set_error("gn stats: memset failed"); return CF_ERR_LAUNCH; }
+        int segs = (int)((L / 4 + 256 * 8 - 1) / (256 * 8));  // ~8 float4 per thread
+        if (segs < 1) segs = 1;
+        if (segs > 64) segs = 64;
+        hipLaunchKernelGGL(gn_stats_block_kernel, dim3((unsigned)(nslabs * segs)), dim3(256), 0, s, x, ws, L, segs);
+    }
+    if (hipGetLastError() != hipSuccess) { set_error("gn stats: launch failed"); return CF_ERR_LAUNCH; }
+    return CF_OK;
+}
+}  // namespace cf
+
 using namespace cf;
+
+static int gn_apply_launch(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C, int HW,
+                           int groups, float eps, int act, int res_mode, const double* ws, hipStream_t s);
 
 extern "C" int cf_group_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,
                              int HW, int groups, float eps, int act, int res_mode, double* ws, void* stream) {
@@ -171,21 +192,24 @@ extern "C" int cf_group_norm(const float* x, const float* gamma, const float* be
     CF_REQUIRE(res_mode == CF_RES_NONE || res, "residual mode %d without residual tensor", res_mode);
     CF_REQUIRE(act >= CF_ACT_NONE && act <= CF_ACT_SIGMOID, "bad activation %d", act);
     hipStream_t s = as_stream(stream);
-    const long nslabs = (long)B * groups;
-    const long Ll = (long)(C / groups) * HW;
-    CF_REQUIRE(Ll < (1L << 31), "slab too large");
-    const int L = (int)Ll;
-    if (L <= 4096 || (L & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) {
-        hipLaunchKernelGGL(gn_stats_wave_kernel, dim3(cdiv(nslabs, 4)), dim3(256), 0, s, x, ws, nslabs, L);
-    } else {
-        hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * nslabs, s);
-        if (e != hipSuccess) { set_error("cf_group_norm: memset failed"); return CF_ERR_LAUNCH; }
-        int segs = (int)((L / 4 + 256 * 8 - 1) / (256 * 8));  // ~8 float4 per thread
-        if (segs < 1) segs = 1;
-        if (segs > 64) segs = 64;
-        hipLaunchKernelGGL(gn_stats_block_kernel, dim3((unsigned)(nslabs * segs)), dim3(256), 0, s, x, ws, L, segs);
-    }
-    CF_CHECK_LAUNCH();
+    CF_REQUIRE((long)(C / groups) * HW < (1L << 31), "slab too large");
+    int rc = launch_gn_stats(x, ws, B, C, HW, groups, s);
+    if (rc != CF_OK) return rc;
+    return gn_apply_launch(x, gamma, beta, res, out, B, C, HW, groups, eps, act, res_mode, ws, s);
+}
+
+// Apply pass only: `ws` already holds the (sum, sum of squares) pairs -- produced by cf_conv2d_f16s' fused epilogue.
+extern "C" int cf_group_norm_apply(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,
+                                   int HW, int groups, float eps, int act, int res_mode, const double* ws, void* stream) {
+    CF_REQUIRE(x && out && ws, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, "bad shape B=%d C=%d HW=%d groups=%d", B, C, HW, groups);
+    CF_REQUIRE(res_mode == CF_RES_NONE || res, "residual mode %d without residual tensor", res_mode);
+    CF_REQUIRE(act >= CF_ACT_NONE && act <= CF_ACT_SIGMOID, "bad activation %d", act);
+    return gn_apply_launch(x, gamma, beta, res, out, B, C, HW, groups, eps, act, res_mode, ws, as_stream(stream));
+}
+
+static int gn_apply_launch(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C, int HW,
+                           int groups, float eps, int act, int res_mode, const double* ws, hipStream_t s) {
     if (HW < 2048) {
         long total = (long)B * C * HW;
         hipLaunchKernelGGL(gn_apply_flat_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, s, x, gamma, beta, res, out, ws, C, HW, groups, eps,

@@ -107,12 +107,16 @@ int cf_conv2d(const float* x1, int C1, const float* x2, int C2, const float* wt,
  * (fp32-class accuracy, measured in DESIGN.md) at up to 5.3x the fp32-MFMA rate.  Supported: 3x3 pad 1 or 1x1 pad 0,
  * stride 1 or 2; anything else returns CF_ERR_ARG and the caller uses cf_conv2d.  `wpk` = weights packed by the host
  * in MFMA fragment order as fp16 hi/lo planes and pre-scaled by 2^s (cineflow/ops.py pack_conv_weight_f16s);
- * pass alpha * 2^-s as `alpha`. */
+ * pass alpha * 2^-s as `alpha`.
+ * gn_ws (nullable, 2*B*gn_groups doubles): on return it holds the GroupNorm / InstanceNorm statistics (sum, sum of squares
+ * per (sample, group)) of the OUTPUT, accumulated in the conv epilogue (or by a statistics pass when a workgroup spans
+ * several samples); feed it to cf_group_norm_apply.  Requires a dense output (out_coff 0, out_ctotal == Cout). */
 int cf_conv2d_f16s(const float* x1, int C1, const float* x2, int C2, const void* wpk, const float* bias, const float* res,
                    float* out, int out_ctotal, int out_coff, int B, int H, int W, int Cout, int KH, int KW, int stride,
-                   int pad_h, int pad_w, int act, float alpha, void* stream);
+                   int pad_h, int pad_w, int act, float alpha, double* gn_ws, int gn_groups, void* stream);
 int cf_conv_transpose2d_k2s2_f16s(const float* x, const void* wpk, const float* bias, float* out, int out_ctotal,
-                                  int out_coff, int B, int Cin, int H, int W, int Cout, float alpha, void* stream);
+                                  int out_coff, int B, int Cin, int H, int W, int Cout, float alpha, double* gn_ws, int gn_groups,
+                                  void* stream);
 
 /* nn.ConvTranspose2d(k=2, s=2) of PatchExpand2DGroup (lib/utils.py:1982-1994) and Generic_UNet.tu
  * (generic_UNet.py:343-345).  w is the torch layout [Cin][Cout][2][2] (no transposition needed); bias nullable.
@@ -126,6 +130,10 @@ int cf_conv_transpose2d_k2s2(const float* x, const float* w, const float* bias, 
  * out = act(gn(x) [+ res]) [+ res]  per res_mode.  In-place (out == x) allowed. */
 int cf_group_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,
                   int HW, int groups, float eps, int act, int res_mode, double* ws, void* stream);
+
+/* The apply pass of cf_group_norm alone; `ws` holds the statistics (from cf_conv2d_f16s' fused epilogue). */
+int cf_group_norm_apply(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,
+                        int HW, int groups, float eps, int act, int res_mode, const double* ws, void* stream);
 
 /* nn.LayerNorm(C) over the channel axis of channel-first tokens x [B,C,N] (lib/vit_transformer.py:1257,1261,1265);
  * the residual add is done by the preceding conv epilogue. */

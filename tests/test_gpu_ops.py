@@ -265,6 +265,35 @@ def test_conv2d_f16s(dev, case):
     assert float(big[:, :2].min()) == 7.0 and float(big[:, 2 + Cout:].max()) == 7.0
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,k,stride,groups", [
+    (2, 16, 32, 32, 64, 3, 1, 8),      # GroupNorm(8, 64): 8 channels per group
+    (3, 32, 64, 64, 32, 3, 1, 32),     # InstanceNorm (one channel per group), narrow kernel variant
+    (2, 64, 64, 64, 128, 3, 2, 8),     # stride 2, 16 channels per group
+    (2, 48, 40, 56, 256, 1, 1, 8),     # 1x1, 32 channels per group, ragged spatial
+    (5, 24, 8, 8, 96, 3, 1, 96),       # 8x8 maps: several samples per workgroup -> statistics pass fallback
+    (2, 64, 33, 47, 512, 3, 1, 8),     # 64 channels per group: a group spans two m-tiles / workgroups
+])
+def test_conv_f16s_fused_group_norm_statistics(dev, B, Cin, H, W, Cout, k, stride, groups):
+    from cineflow import ops
+    x = randn(B, Cin, H, W, seed=45)
+    w = randn(Cout, Cin, k, k, seed=46) / math.sqrt(Cin * k * k)
+    b = randn(Cout, seed=47)
+    g, be = 1 + 0.1 * randn(Cout, seed=48), 0.1 * randn(Cout, seed=49)
+    y = F.conv2d(x, w, b, stride=stride, padding=k // 2)
+    ref = F.gelu(F.group_norm(y, groups, g, be, 1e-5))
+    wpk, ws_ = ops.pack_conv_weight_f16s(w.to(dev))
+    out, stats = ops.conv2d_f16s(x.to(dev), wpk, ws_, b.to(dev), Cout, k, k, stride, (k // 2, k // 2), stats_groups=groups)
+    check(out, y, 2e-5, "conv")
+    cpg = Cout // groups
+    yo = out.cpu().double()  # the statistics are those of the stored values
+    want = torch.stack([yo.view(B, groups, -1).sum(-1), (yo ** 2).view(B, groups, -1).sum(-1)], -1)
+    scale = yo.abs().view(B, groups, -1).sum(-1)[..., None] + 1.0
+    rel = float(((stats.cpu().view(B, groups, 2) - want).abs() / scale).max())
+    assert rel <= 2e-6, rel
+    res = ops.group_norm_apply(out, g.to(dev), be.to(dev), groups, stats, act="gelu")
+    check(res, ref, 3e-5, "gn apply on fused statistics")
+
+
 def test_conv_f16s_dynamic_range(dev):
     """tiny and large operands: the weight pre-scaling keeps the lo halves normal; activations lose <= 2^-25 absolute."""
     from cineflow import ops
