@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--slices", type=int, default=16, help="cine slices per step and per GPU (B)")
+    ap.add_argument("--slices", type=int, default=32, help="cine slices per step and per GPU (B)")
     ap.add_argument("--frames", type=int, default=30, help="frames per cine slice (T)")
     ap.add_argument("--variant", default="video", choices=["video", "raft_config"])
     ap.add_argument("--seg-chunk", type=int, default=120)
