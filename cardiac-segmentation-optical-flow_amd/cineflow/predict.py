@@ -1,0 +1,348 @@
+"""Predict-from-folder API of the reference, on the HIP path.
+
+Mirrors `nnunet/inference/predict.py` (public names, argument lists and defaults of `predict_from_folder` :665-672,
+`predict_cases` :228-232, `check_input_folder_and_return_caseIDs` :629, the CLI flags of :782-858) and the output
+layout the downstream scripts read (`<out>/<patient>/{Segmentation,Registered}/<case>.nii.gz` uint8 and
+`<out>/<patient>/Flow/<case>.npz` with `flow` float32 `[Y,X,Z,2]` + `spacing`, segmentation_export.py:190-219).
+
+Differences that are deliberate and documented in DESIGN.md:
+  * every patient folder is processed (the reference `return`s from inside its patient loop, predict.py:743);
+  * the model folder holds `plans.json` + `fold_X/<chk>.model` written by `save_model_folder` below (a plain tensor
+    dict, loaded with `torch.load(weights_only=True)`); the reference's `plans.pkl` / `*.model.pkl` are pickles of
+    trainer objects whose classes cannot be imported here, and nothing on this path un-pickles;
+  * preprocessing is the z-score of the volume at native spacing (crop-to-nonzero and resampling are the "next" rows
+    of SURVEY.md section 8f), so the exporter needs no resampling either; the heart centroid of `Processor` comes from
+    the image centre because the reference's 2-class cropping network is outside this path;
+  * when no ED label map is supplied the ED segmentation predicted by the U-Net is the one propagated.
+"""
+import argparse
+import csv
+import json
+import os
+import shutil
+from copy import deepcopy
+from multiprocessing.pool import ThreadPool
+
+import numpy as np
+import torch
+
+from . import ops
+from .inference import Processor, chunk_orders, normalize_intensity_, pad_nd_image, predict_3D_2Dconv_tiled, predict_cine_slices
+from .models import Generic_UNet, SegFlowGaussian
+from .nifti import read_nifti, write_nifti
+
+join = os.path.join
+
+
+# ------------------------------------------------------------------------------------------------ model folder
+def save_model_folder(folder, seg_net, flow_net, plans, fold=0, checkpoint_name="model_final_checkpoint", seg_sd=None, flow_sd=None):
+    """Write `<folder>/plans.json` and `<folder>/fold_<fold>/<checkpoint_name>.model` (state dicts keyed by the
+    reference's parameter names).  `seg_sd` / `flow_sd`: {name: tensor}."""
+    os.makedirs(join(folder, "fold_%d" % fold), exist_ok=True)
+    with open(join(folder, "plans.json"), "w") as f:
+        json.dump(plans, f, indent=1)
+    torch.save({"seg_state_dict": {k: v.cpu() for k, v in seg_sd.items()}, "flow_state_dict": {k: v.cpu() for k, v in flow_sd.items()}},
+               join(folder, "fold_%d" % fold, checkpoint_name + ".model"))
+
+
+def default_plans(image_size=256, crop_size=None, flow_variant="video", seg_base=32, seg_pool=6, reduced=None):
+    p = {"num_modalities": 1, "num_classes": 4, "patch_size": [image_size, image_size], "transpose_forward": [0, 1, 2],
+         "transpose_backward": [0, 1, 2], "mirror_axes": [0, 1], "crop_size": crop_size or image_size, "image_size": image_size,
+         "seg_net": {"base_num_features": seg_base, "num_pool": seg_pool},
+         "flow_net": {"variant": flow_variant, "kwargs": reduced or {}}}
+    return p
+
+
+class CineTrainer:
+    """Duck-types the trainer interface `predict_cases` uses (predict.py:285-354, :1028-1091)."""
+
+    def __init__(self, plans, device):
+        self.plans = plans
+        self.device = device
+        self.num_classes = plans["num_classes"]
+        self.data_aug_params = {"mirror_axes": tuple(plans["mirror_axes"])}
+        self.patch_size = tuple(plans["patch_size"])
+        self.processor = Processor(crop_size=plans["crop_size"], image_size=plans["patch_size"][0])
+        sk = plans["seg_net"]
+        self.seg_net = Generic_UNet(plans["num_modalities"], sk["base_num_features"], self.num_classes, sk["num_pool"])
+        fk = plans["flow_net"]
+        ma = fk["variant"] == "raft_config"
+        kw = dict(image_size=plans["crop_size"], motion_appearance=ma, dim_feedforward=3072 if ma else 2048)
+        kw.update(fk.get("kwargs", {}))
+        self.flow_net = SegFlowGaussian(**kw)
+
+    # -- network_trainer.py:418 load_checkpoint_ram(params, train)
+    def load_checkpoint_ram(self, params, train=False):
+        self.seg_net.load_state_dict(params["seg_state_dict"], self.device)
+        self.flow_net.load_state_dict(params["flow_state_dict"], self.device)
+
+    # -- nnUNetTrainer.py:571-597 preprocess_patient(list_of_files) -> (data[C,Z,Y,X], seg, properties)
+    def preprocess_patient(self, input_files):
+        vols, props = [], None
+        for f in input_files:
+            a, pr = read_nifti(f)
+            vols.append(a.astype(np.float32))
+            props = props or pr
+        data = np.stack(vols, 0)
+        properties = dict(props)
+        properties.update(original_size_of_raw_data=np.array(data.shape[1:]), original_spacing=np.array(props["itk_spacing"])[::-1],
+                          list_of_data_files=list(input_files), crop_bbox=None, size_after_cropping=np.array(data.shape[1:]),
+                          size_after_resampling=np.array(data.shape[1:]), spacing_after_resampling=np.array(props["itk_spacing"])[::-1])
+        for c in range(data.shape[0]):
+            m, s = data[c].mean(), data[c].std()
+            data[c] = (data[c] - m) / (s + 1e-8)
+        return data, None, properties
+
+    # -- nnUNetTrainer.py:637-679
+    def predict_preprocessed_data_return_seg_and_softmax(self, data, do_mirroring=True, mirror_axes=None, use_sliding_window=True,
+                                                         step_size=0.5, use_gaussian=True, pad_border_mode="constant", pad_kwargs=None,
+                                                         all_in_gpu=False, verbose=True, mixed_precision=True):
+        mirror_axes = self.data_aug_params["mirror_axes"] if mirror_axes is None else mirror_axes
+        return predict_3D_2Dconv_tiled(self.seg_net, data, self.patch_size, step_size=step_size, do_mirroring=do_mirroring,
+                                       mirror_axes=mirror_axes, use_gaussian=use_gaussian, pad_border_mode=pad_border_mode,
+                                       pad_kwargs=pad_kwargs)
+
+    # -- nnUNetTrainer.py:682-726 -> SegFlowGaussian.predict_3D_flow :2837, _internal_predict_2D_2Dconv_tiled_flow :3294-3533
+    def predict_preprocessed_data_return_seg_and_softmax_flow(self, unlabeled, target=None, target_mask=None, processor=None,
+                                                              do_mirroring=True, mirror_axes=None, use_sliding_window=True, step_size=0.5,
+                                                              use_gaussian=True, pad_border_mode="constant", pad_kwargs=None,
+                                                              all_in_gpu=False, verbose=True, mixed_precision=True, centroid=None):
+        """unlabeled [T,1,Z,Y,X] (numpy) -> (seg [T,Z,Y,X], softmax [T,K,Z,Y,X], flow [T,2,Z,Y,X], registered [T,1,Z,Y,X],
+        raw [T,3,Z,crop,crop]).  target: optional ED label volume [Z,Y,X]."""
+        processor = processor or self.processor
+        mirror_axes = self.data_aug_params["mirror_axes"] if mirror_axes is None else mirror_axes
+        T, _, Z, Y, X = unlabeled.shape
+        P = self.patch_size
+        x = unlabeled[:, 0]                                                            # [T,Z,Y,X]
+        data, slicer = pad_nd_image(x, P, pad_border_mode, pad_kwargs, True)            # SegFlowGaussian.py:3310
+        Hp, Wp = data.shape[-2:]
+        y1, y2 = int(Hp / 2 - P[0] / 2), int(Hp / 2 + P[0] / 2)                         # :3391-3397 centre crop to the patch
+        x1, x2 = int(Wp / 2 - P[1] / 2), int(Wp / 2 + P[1] / 2)
+        dev = self.device
+        patch = torch.from_numpy(np.ascontiguousarray(data[:, :, y1:y2, x1:x2])).to(dev, dtype=torch.float32)   # [T,Z,P,P]
+        cs = processor.crop_size
+        cen = centroid if centroid is not None else (P[1] // 2, P[0] // 2)              # (x, y): image centre (see module docstring)
+        win = processor.adjust_cropping_window(cen)
+        cx0, cx1, cy0, cy1 = win["crop_indices"]
+        crop = ops.crop2d(patch, cy0, cx0, cs, cs)                                      # [T,Z,cs,cs]
+        for z in range(Z):                                                              # :3108 NormalizeIntensity on each slice's [T,h,w] block
+            blk = crop[:, z].contiguous()
+            normalize_intensity_(blk)
+            crop[:, z] = blk
+        frames = crop.view(T, Z, 1, cs, cs)
+        ed = None
+        if target is not None:
+            tp = pad_nd_image(np.asarray(target)[None], P, "constant", {"constant_values": 0}, False)[0]
+            ed = torch.from_numpy(np.ascontiguousarray(tp[:, y1:y2, x1:x2][:, cy0:cy1, cx0:cx1])).to(dev, dtype=torch.uint8)
+        out = predict_cine_slices(self.flow_net, self.seg_net, frames, ed, do_mirroring, mirror_axes)
+        pad_need = win["padding_need"]
+
+        def place(t):  # [..., cs, cs] -> [..., Y, X]: uncrop (processor.py:178-186), centre window, un-pad
+            full = processor.uncrop_no_registration(t, pad_need)
+            canvas = torch.zeros(tuple(full.shape[:-2]) + (Hp, Wp), dtype=full.dtype, device=dev)
+            canvas[..., y1:y2, x1:x2] = full
+            return canvas[..., slicer[-2], slicer[-1]]
+
+        softmax = place(out["softmax"].permute(0, 2, 1, 3, 4).contiguous())            # [T,K,Z,Y,X]
+        flow = place(out["flow"].permute(0, 2, 1, 3, 4).contiguous())                  # [T,2,Z,Y,X]
+        reg = place(out["registered"].float())[:, None]                                # [T,1,Z,Y,X]
+        seg = ops.argmax_channels(softmax.reshape(T, self.num_classes, -1).contiguous()).view(T, Z, Y, X)
+        raw = torch.cat([frames.permute(0, 2, 1, 3, 4), out["flow"].permute(0, 2, 1, 3, 4)], 1)
+        return seg.cpu().numpy(), softmax.cpu().numpy(), flow.cpu().numpy(), reg.cpu().numpy(), raw.cpu().numpy()
+
+
+def load_model_and_checkpoint_files(folder, folds=None, mixed_precision=None, checkpoint_name="model_final_checkpoint", device=None):
+    """model_restore.py:109-155 equivalent for the plans.json / *.model folder format -> (trainer, [params per fold])."""
+    assert os.path.isfile(join(folder, "plans.json")), "Folder with saved model weights must contain a plans.json file"
+    with open(join(folder, "plans.json")) as f:
+        plans = json.load(f)
+    if folds is None or folds == "None":
+        folds = sorted(d for d in os.listdir(folder) if d.startswith("fold_"))
+    elif isinstance(folds, (list, tuple)):
+        folds = ["fold_%s" % i if str(i) != "all" else "all" for i in folds]
+    else:
+        folds = ["fold_%s" % folds]
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    trainer = CineTrainer(plans, device)
+    params = [torch.load(join(folder, f, checkpoint_name + ".model"), map_location="cpu", weights_only=True) for f in folds]
+    return trainer, params
+
+
+# ------------------------------------------------------------------------------------------------ export
+def save_segmentation_nifti_from_softmax(segmentation_softmax, out_fname, properties_dict, order=1, region_class_order=None,
+                                         seg_postprogess_fn=None, seg_postprocess_args=None, resampled_npz_fname=None,
+                                         non_postprocessed_fname=None, force_separate_z=None, interpolation_order_z=0, verbose=True,
+                                         flow=None, flow_path=None, registered=None, registered_path=None):
+    """segmentation_export.py:29-223 for the no-resampling case: argmax -> uint8 NIfTI with the case's geometry;
+    flow [2,Z,Y,X] -> npz `flow` [Y,X,Z,2] float32 + `spacing`; registered [1,Z,Y,X] -> uint8 NIfTI."""
+    if isinstance(segmentation_softmax, str):
+        segmentation_softmax = np.load(segmentation_softmax)
+    shape = tuple(properties_dict.get("size_after_cropping"))
+    assert tuple(segmentation_softmax.shape[1:]) == shape, "resampling on export is not built yet (SURVEY section 8f row 1)"
+    if resampled_npz_fname is not None:
+        np.savez_compressed(resampled_npz_fname, softmax=segmentation_softmax.astype(np.float16))
+    seg = segmentation_softmax.argmax(0).astype(np.uint8)
+    geo = (properties_dict["itk_spacing"], properties_dict["itk_origin"], properties_dict["itk_direction"])
+    write_nifti(out_fname, seg, *geo)
+    if flow is not None:
+        np.savez(flow_path, flow=np.asarray(flow, np.float32).transpose(2, 3, 1, 0), spacing=properties_dict["itk_spacing"])
+    if registered is not None:
+        write_nifti(registered_path, np.asarray(registered[0]).astype(np.uint8), *geo)
+
+
+# ------------------------------------------------------------------------------------------------ predict API
+def subfiles(folder, suffix=None, join_=True, sort=True):
+    res = [f for f in os.listdir(folder) if os.path.isfile(join(folder, f)) and (suffix is None or f.endswith(suffix))]
+    if sort:
+        res.sort()
+    return [join(folder, f) for f in res] if join_ else res
+
+
+def check_input_folder_and_return_caseIDs(input_folder, expected_num_modalities):
+    """predict.py:629-662, message for message."""
+    print("This model expects %d input modalities for each image" % expected_num_modalities)
+    files = subfiles(input_folder, suffix=".nii.gz", join_=False, sort=True)
+    maybe_case_ids = np.unique([i[:-12] for i in files])
+    remaining = deepcopy(files)
+    missing = []
+    assert len(files) > 0, "input folder did not contain any images (expected to find .nii.gz file endings)"
+    for c in maybe_case_ids:
+        for n in range(expected_num_modalities):
+            expected_output_file = c + "_%04.0d.nii.gz" % n
+            if not os.path.isfile(join(input_folder, expected_output_file)):
+                missing.append(expected_output_file)
+            else:
+                remaining.remove(expected_output_file)
+    print("Found %d unique case ids, here are some examples:" % len(maybe_case_ids),
+          np.random.choice(maybe_case_ids, min(len(maybe_case_ids), 10)))
+    print("If they don't look right, make sure to double check your filenames. They must end with _0000.nii.gz etc")
+    if len(remaining) > 0:
+        print("found %d unexpected remaining files in the folder. Here are some examples:" % len(remaining),
+              np.random.choice(remaining, min(len(remaining), 10)))
+    if len(missing) > 0:
+        print("Some files are missing:")
+        print(missing)
+        raise RuntimeError("missing files in input_folder")
+    return maybe_case_ids
+
+
+def _subfolder_path(path, sub):
+    """predict.py:1059-1068 inserts the sub-folder as path component 2 of a relative path; this is the same place for
+    `<out>/<patient>/<case>` and also works for absolute / nested output folders."""
+    return join(os.path.dirname(path), sub, os.path.basename(path))
+
+
+def predict_cases(model, list_of_lists, output_filenames, folds, save_npz, num_threads_preprocessing, num_threads_nifti_save,
+                  segs_from_prev_stage=None, do_tta=True, mixed_precision=True, overwrite_existing=False, all_in_gpu=False,
+                  step_size=0.5, checkpoint_name="model_final_checkpoint", segmentation_export_kwargs=None,
+                  disable_postprocessing=False, ed_index=0):
+    """predict.py:228-354 + predict_flow :1008-1130 for ONE patient: `list_of_lists[t]` = the modality files of frame t.
+    All frames form the cine sequence; frame `ed_index` is rotated to the front for the ED-anchored recurrence."""
+    assert len(list_of_lists) == len(output_filenames)
+    trainer, params = load_model_and_checkpoint_files(model, folds, mixed_precision=mixed_precision, checkpoint_name=checkpoint_name)
+    trainer.load_checkpoint_ram(params[0], False)
+    for o in output_filenames:
+        for sub in ("Segmentation", "Flow", "Registered"):
+            os.makedirs(join(os.path.dirname(o), sub), exist_ok=True)
+    pre = [trainer.preprocess_patient(l) for l in list_of_lists]                # predict.py:302
+    d = [p[0] for p in pre]
+    property_list = [p[2] for p in pre]
+    T = len(d)
+    order = list(range(ed_index, T)) + list(range(0, ed_index))                 # ED first (trainer SegFlowGaussian.py:1005-1013)
+    unlabeled = np.stack([d[i] for i in order]) + 1e-8                           # predict.py:1025
+    print("predicting", output_filenames)
+    seg, softmax, flow, registered, _raw = trainer.predict_preprocessed_data_return_seg_and_softmax_flow(
+        unlabeled=unlabeled, target=None, target_mask=None, processor=trainer.processor, do_mirroring=do_tta,
+        mirror_axes=trainer.data_aug_params["mirror_axes"], use_sliding_window=True, step_size=step_size, use_gaussian=True,
+        all_in_gpu=all_in_gpu, mixed_precision=mixed_precision, verbose=False)
+    pool = ThreadPool(max(1, num_threads_nifti_save))
+    jobs = []
+    for j, t in enumerate(order):
+        out = output_filenames[t]
+        seg_path, flow_path, reg_path = (_subfolder_path(out, s) for s in ("Segmentation", "Flow", "Registered"))
+        npz = seg_path[:-7] + ".npz" if save_npz else None
+        jobs.append(pool.apply_async(save_segmentation_nifti_from_softmax,
+                                     (softmax[j], seg_path, property_list[t], 1, None, None, None, npz, None, None, 0, False, flow[j],
+                                      flow_path[:-7] + ".npz", registered[j], reg_path)))
+    [j.get() for j in jobs]
+    pool.close()
+    pool.join()
+    return [(_subfolder_path(o, "Segmentation"), _subfolder_path(o, "Flow")[:-7] + ".npz", _subfolder_path(o, "Registered"))
+            for o in output_filenames]
+
+
+def predict_from_folder(model, input_folder, output_folder, folds, save_npz, num_threads_preprocessing, num_threads_nifti_save,
+                        lowres_segmentations, part_id, num_parts, tta, mixed_precision=True, overwrite_existing=True, mode="normal",
+                        overwrite_all_in_gpu=None, step_size=0.5, checkpoint_name="model_final_checkpoint",
+                        segmentation_export_kwargs=None, disable_postprocessing=False):
+    """predict.py:665-780.  Patients are sharded `patients[part_id::num_parts]` (one process per GPU); every patient of
+    the shard is processed."""
+    os.makedirs(output_folder, exist_ok=True)
+    assert os.path.isfile(join(model, "plans.json")), "Folder with saved model weights must contain a plans.json file"
+    shutil.copy(join(model, "plans.json"), output_folder)
+    with open(join(model, "plans.json")) as f:
+        expected_num_modalities = json.load(f)["num_modalities"]
+    if mode not in ("normal", "fast", "fastest"):
+        raise ValueError("unrecognized mode. Must be normal, fast or fastest")
+    patients = sorted(p for p in os.listdir(input_folder) if os.path.isdir(join(input_folder, p)))
+    results = {}
+    for patient in patients[part_id::num_parts]:
+        current_input_folder = join(input_folder, patient)
+        current_output_folder = join(output_folder, patient)
+        for sub in ("Flow", "Registered", "Segmentation"):
+            os.makedirs(join(current_output_folder, sub), exist_ok=True)
+        case_ids = check_input_folder_and_return_caseIDs(current_input_folder, expected_num_modalities)
+        output_files = [join(current_output_folder, i + ".nii.gz") for i in case_ids]
+        all_files = subfiles(current_input_folder, suffix=".nii.gz", join_=False, sort=True)
+        list_of_lists = [[join(current_input_folder, i) for i in all_files if i[:len(j)].startswith(j) and len(i) == (len(j) + 12)]
+                         for j in case_ids]
+        ed_index = 0
+        csv_path = join(current_input_folder, patient + ".csv")                  # predict.py:700, :1196-1198
+        if os.path.isfile(csv_path):
+            with open(csv_path) as f:
+                rows = list(csv.DictReader(f))
+            if rows and "ed_index" in rows[0]:
+                ed_index = int(float(rows[0]["ed_index"]))
+        results[patient] = predict_cases(model, list_of_lists, output_files, folds, save_npz, num_threads_preprocessing,
+                                         num_threads_nifti_save, None, tta, mixed_precision=mixed_precision,
+                                         overwrite_existing=overwrite_existing, all_in_gpu=bool(overwrite_all_in_gpu), step_size=step_size,
+                                         checkpoint_name=checkpoint_name, segmentation_export_kwargs=segmentation_export_kwargs,
+                                         disable_postprocessing=disable_postprocessing, ed_index=ed_index)
+    return results
+
+
+def main(argv=None):
+    """CLI flags of predict.py:782-858 / predict_simple.py:34-131."""
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-i", "--input_folder", required=True)
+    parser.add_argument("-o", "--output_folder", required=True)
+    parser.add_argument("-m", "--model_output_folder", required=True)
+    parser.add_argument("-f", "--folds", nargs="+", default="None")
+    parser.add_argument("-z", "--save_npz", required=False, action="store_true")
+    parser.add_argument("-l", "--lowres_segmentations", required=False, default="None")
+    parser.add_argument("--part_id", type=int, required=False, default=0)
+    parser.add_argument("--num_parts", type=int, required=False, default=1)
+    parser.add_argument("--num_threads_preprocessing", required=False, default=6, type=int)
+    parser.add_argument("--num_threads_nifti_save", required=False, default=2, type=int)
+    parser.add_argument("--tta", required=False, type=int, default=1)
+    parser.add_argument("--disable_tta", required=False, default=False, action="store_true")
+    parser.add_argument("--overwrite_existing", required=False, type=int, default=1)
+    parser.add_argument("--mode", type=str, default="normal", required=False)
+    parser.add_argument("--all_in_gpu", type=str, default="None", required=False)
+    parser.add_argument("--step_size", type=float, default=0.5, required=False)
+    parser.add_argument("--disable_mixed_precision", default=False, action="store_true", required=False)
+    parser.add_argument("-chk", default="model_final_checkpoint", required=False)
+    a = parser.parse_args(argv)
+    folds = a.folds if a.folds != "None" and a.folds != ["None"] else None
+    if isinstance(folds, list):
+        folds = [int(i) if i != "all" else i for i in folds]
+    all_in_gpu = None if a.all_in_gpu == "None" else a.all_in_gpu == "True"
+    tta = bool(a.tta) and not a.disable_tta
+    return predict_from_folder(a.model_output_folder, a.input_folder, a.output_folder, folds, a.save_npz, a.num_threads_preprocessing,
+                               a.num_threads_nifti_save, None, a.part_id, a.num_parts, tta, mixed_precision=not a.disable_mixed_precision,
+                               overwrite_existing=bool(a.overwrite_existing), mode=a.mode, overwrite_all_in_gpu=all_in_gpu,
+                               step_size=a.step_size, checkpoint_name=a.chk)
+
+
+if __name__ == "__main__":
+    main()

@@ -420,10 +420,10 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     const bool k3 = p.KH == 3;
     const int CK = k3 ? 16 : 32;
     const bool narrow = p.Cout <= 32;
-    const bool small = f16s_small_tile() && !narrow;
+    const bool small = f16s_small_tile() != 0;
     const bool s2 = k3 && p.stride == 2;
     // n-tiles (of 32 output pixels) per workgroup
-    const int NT_WG = s2 ? (small ? 2 : 4) : (small ? 4 : 8);
+    const int NT_WG = s2 ? ((small && !narrow) ? 2 : 4) : (small ? 4 : 8);
     const int npx = NT_WG * 32;
     F16sGeom g;
     g.TW = p.Wo < 32 ? p.Wo : 32;
@@ -449,7 +449,7 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     }
     // keep the staging work within the per-thread task budget of the variant (MAXT x 256 eight-channel tasks)
     {
-        const int maxt = small ? (s2 ? 3 : 2) : (s2 ? 5 : 4);
+        const int maxt = s2 ? ((small && !narrow) ? 3 : 5) : (small ? 2 : 4);
         while (g.NIMG > 1 && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 > maxt) --g.NIMG;
     }
     g.tiles_x = (p.Wo + g.TW - 1) / g.TW;
@@ -460,8 +460,9 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
         *one_sample_per_wg = g.NIMG == 1;
         return CF_OK;
     }
-    if (small && s2) return launch_f16s<9, 16, 2, 1, 3>(p, g, wpk, s);
-    if (small) return k3 ? launch_f16s<9, 16, 2, 2, 2>(p, g, wpk, s) : launch_f16s<1, 32, 2, 2, 2>(p, g, wpk, s);
+    if (small && narrow && !s2) return k3 ? launch_f16s<9, 16, 1, 1, 2>(p, g, wpk, s) : launch_f16s<1, 32, 1, 1, 2>(p, g, wpk, s);
+    if (small && s2 && !narrow) return launch_f16s<9, 16, 2, 1, 3>(p, g, wpk, s);
+    if (small && !narrow) return k3 ? launch_f16s<9, 16, 2, 2, 2>(p, g, wpk, s) : launch_f16s<1, 32, 2, 2, 2>(p, g, wpk, s);
     if (k3) {
         if (p.stride == 1) return narrow ? launch_f16s<9, 16, 1, 2, 4>(p, g, wpk, s) : launch_f16s<9, 16, 2, 4, 4>(p, g, wpk, s);
         return narrow ? launch_f16s<9, 16, 1, 1, 5>(p, g, wpk, s) : launch_f16s<9, 16, 2, 2, 5>(p, g, wpk, s);

