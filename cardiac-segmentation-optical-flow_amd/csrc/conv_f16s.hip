@@ -51,20 +51,29 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
-template <int KHW, int CK, int WM, int NTW, int MAXT>
-__global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restrict__ wpk) {
+// NLW = number of dedicated loader waves.  NLW == 0: all four waves stage and compute (first design).  NLW > 0: waves
+// 0-3 only run MFMAs (their vmcnt queue holds nothing but weight fragments), waves 4.. only stage the input patch, two
+// chunks of loads in flight, always one LDS buffer ahead.  vmcnt retires in issue order, so in the mixed design every
+// wait for a weight fragment also waited for the staging loads issued before it (ablating those loads made the kernel
+// 19-33 % faster); with separate roles nothing in the MFMA waves ever waits for HBM.
+template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW>
+__global__ void __launch_bounds__(256 + 64 * NLW, NLW ? 5 : ((NTW <= 2 && MAXT <= 3) ? 4 : 2))
+conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restrict__ wpk) {
     constexpr int KW = (KHW == 9) ? 3 : 1;
     constexpr int KS = CK / 16;            // MFMA k-steps per tap per chunk
     constexpr int REC = CK * 4 + 16;       // bytes per pixel record
     constexpr int NT_WG = NTW * (4 / WM);  // n-tiles per workgroup
     constexpr int NG = CK / 8;             // 8-channel groups per record
+    constexpr int NSTAGE = NLW ? 64 * NLW : 256;   // threads that stage
+    (void)NT_WG;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
+    const bool loader = NLW > 0 && wave >= 4;      // wave-uniform
     const int mt = blockIdx.y * WM + (WM == 2 ? (wave & 1) : 0);  // 32-channel m-tile of this wave
-    const int ngrp = (WM == 2) ? (wave >> 1) : wave;              // n-tile group of this wave
+    const int ngrp = (WM == 2) ? ((wave & 3) >> 1) : (wave & 3);  // n-tile group of this wave
 
     // ---- workgroup tile decode (XCD-banded so that vertically adjacent tiles share one L2)
     int bid = blockIdx.x;
@@ -80,30 +89,35 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
     const int x0 = tx * g.TW, y0 = ty * g.TH, b0 = bg * g.NIMG;
     const int HW = p.H * p.W;
     const int HoWo = p.Ho * p.Wo;
-    const int Cin = p.C1 + p.C2;
     const int iy_org = y0 * p.stride - p.pad_h, ix_org = x0 * p.stride - p.pad_w;
     const int nrec = g.NIMG * g.PH * g.PW;
     const int buf_bytes = nrec * REC;
+    const bool do_stats = p.gn_ws != nullptr;
 
-    // ---- staging task descriptors (fixed over the channel loop).  Inputs are read with raw buffer loads: the per-lane
-    // 32-bit byte offset of (sample, channel 0, iy, ix) is computed once per task, the channel term is added per load,
-    // and the descriptor's range check returns 0 for (a) pixels outside the image / batch, whose offset is parked at
-    // 2 GiB, and (b) channel reads past the end of the tensor.  (Channels >= Cin that still fall inside the tensor read
-    // finite data of the next sample; their packed weights are exactly zero.)  Host checks: tensors < 2 GiB, and
-    // C1 % CK == 0 when x2 is present so a chunk never straddles the two inputs.
+    // =================================================================================================================
+    // staging role (all waves when NLW == 0, waves 4.. otherwise)
+    // =================================================================================================================
+    // Inputs are read with raw buffer loads: the per-lane 32-bit byte offset of (sample, channel 0, iy, ix) is computed
+    // once per task, the channel term is added per load, and the descriptor's range check returns 0 for (a) pixels
+    // outside the image / batch, whose offset is parked at 2 GiB, and (b) channel reads past the end of the tensor.
+    // (Channels >= Cin that still fall inside the tensor read finite data of the next sample; their packed weights are
+    // exactly zero.)  Host checks: tensors < 2 GiB, and C1 % CK == 0 when x2 is present.
     constexpr unsigned OOB = 0x80000000u;
     unsigned t_o1[MAXT], t_o2[MAXT];  // byte offsets into x1 / x2 (OOB when invalid)
     int t_lds[MAXT];                  // byte offset of the 16-byte hi slot inside a buffer, -1: no task
     unsigned t_g8[MAXT];              // (8-channel group inside the chunk) * 8
+    const int stid = NLW ? tid - 256 : tid;
+    const bool stages = NLW ? loader : true;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-        int task = tid + t * 256;
-        int grp = task / nrec;
-        int pr = task - grp * nrec;
         t_o1[t] = OOB;
         t_o2[t] = OOB;
         t_lds[t] = -1;
         t_g8[t] = 0;
+        if (!stages) continue;
+        int task = stid + t * NSTAGE;
+        int grp = task / nrec;
+        int pr = task - grp * nrec;
         if (grp < NG) {
             int img = pr / (g.PH * g.PW);
             int q = pr - img * (g.PH * g.PW);
@@ -124,6 +138,68 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x2 ? p.x2 : p.x1), 0, p.x2 ? (int)((long)p.B * p.C2 * HW * 4) : 0, 0x00020000);
     const unsigned HW4 = (unsigned)HW * 4u;
 
+    // The loaded values stay RAW in registers until the LDS write (nothing consumes a load result early).
+    auto issue_loads = [&](int chunk, float (&stg)[MAXT][8]) {
+        const int c0 = chunk * CK;
+        const bool in1 = c0 < p.C1;                       // workgroup-uniform
+        const unsigned cb = (unsigned)(in1 ? c0 : c0 - p.C1);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const unsigned v0 = (in1 ? t_o1[t] : t_o2[t]) + (cb + t_g8[t]) * HW4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned off = v0 + (unsigned)j * HW4;
+                const unsigned raw = in1 ? __builtin_amdgcn_raw_buffer_load_b32(rsrc1, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b32(rsrc2, off, 0, 0);
+                stg[t][j] = __builtin_bit_cast(float, raw);
+            }
+        }
+    };
+    auto write_stage = [&](int chunk, const float (&stg)[MAXT][8]) {
+        unsigned char* base = lds + (chunk & 1) * buf_bytes;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            if (t_lds[t] < 0) continue;
+            f16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 h, l;
+                split_f16(stg[t][j], h, l);
+                hi[j] = h;
+                lo[j] = l;
+            }
+            *reinterpret_cast<f16x8*>(base + t_lds[t]) = hi;
+            *reinterpret_cast<f16x8*>(base + t_lds[t] + CK * 2) = lo;
+        }
+    };
+
+    if (NLW > 0 && loader) {
+        // ---- loader waves: two register sets keep TWO chunks of loads in flight (loop unrolled by two so the sets are
+        // statically indexed); the wait in front of each LDS write is for loads issued a whole chunk period earlier.
+        // Barrier count must equal the MFMA branch: 1 + nchunk (+ 3 when statistics are fused).
+        float sa[MAXT][8], sb[MAXT][8];
+        const int n = g.nchunk;
+        issue_loads(0, sa);
+        if (n > 1) issue_loads(1, sb);
+        write_stage(0, sa);
+        __syncthreads();
+        int c = 0;
+        while (true) {
+            if (c + 2 < n) issue_loads(c + 2, sa);
+            if (c + 1 < n) write_stage(c + 1, sb);
+            __syncthreads();
+            if (++c >= n) break;
+            if (c + 2 < n) issue_loads(c + 2, sb);
+            if (c + 1 < n) write_stage(c + 1, sa);
+            __syncthreads();
+            if (++c >= n) break;
+        }
+        if (do_stats) { __syncthreads(); __syncthreads(); __syncthreads(); }
+        return;
+    }
+
+    // =================================================================================================================
+    // MFMA role
+    // =================================================================================================================
     // ---- per-lane B-fragment record offsets and output coordinates of this wave's n-tiles
     int b_rec[NTW];
     bool o_ok[NTW];
@@ -155,50 +231,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
     // packed weights: fragment (mt, chunk, tap, ks, part) = 64 lanes x 8 halves
     const f16x8* wfrag = reinterpret_cast<const f16x8*>(wpk) + (long)mt * g.nchunk * (KHW * KS * 2) * 64 + lane;
 
-    float stg[MAXT][8];
-
-    // Loads are unconditional (clamped address, select on the VALUE): a per-element conditional load would make hipcc
-    // branch around every load and drain vmcnt(0) each time (cdna_hip_programming.md section 5, trap c).  C1 % 8 == 0 is
-    // required when x2 is present (host-checked), so an 8-channel group never straddles the two inputs.
-    // The loaded values stay RAW in registers across the MFMA section (nothing consumes a load result early), and are
-    // split into fp16 hi/lo at write time.
-    auto issue_loads = [&](int chunk) {
-        const int c0 = chunk * CK;
-        const bool in1 = c0 < p.C1;                       // workgroup-uniform
-        const unsigned cb = (unsigned)(in1 ? c0 : c0 - p.C1);
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            const unsigned v0 = (in1 ? t_o1[t] : t_o2[t]) + (cb + t_g8[t]) * HW4;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned off = v0 + (unsigned)j * HW4;
-                const unsigned raw = in1 ? __builtin_amdgcn_raw_buffer_load_b32(rsrc1, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b32(rsrc2, off, 0, 0);
-                stg[t][j] = __builtin_bit_cast(float, raw);
-            }
-        }
-    };
-    auto write_stage = [&](int chunk) {
-        unsigned char* base = lds + (chunk & 1) * buf_bytes;
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t) {
-            if (t_lds[t] < 0) continue;
-            f16x8 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                _Float16 h, l;
-                split_f16(stg[t][j], h, l);
-                hi[j] = h;
-                lo[j] = l;
-            }
-            *reinterpret_cast<f16x8*>(base + t_lds[t]) = hi;
-            *reinterpret_cast<f16x8*>(base + t_lds[t] + CK * 2) = lo;
-        }
-    };
-
-    // A-fragment register ring.  vmcnt retires in issue order, so a wait for an A fragment also waits for every staging
-    // load issued before it: the ring is prefetched D steps ahead so that the fragments consumed during the first D+1
-    // steps of a chunk were issued BEFORE that chunk's staging loads, which leaves those loads D+1 MFMA steps (plus the
-    // co-resident wave's) to land before the first wait that covers them.  NSTEP % R == 0 keeps the slots static.
+    // A-fragment register ring, prefetched D steps ahead (NSTEP % R == 0 keeps the slots static).
     constexpr int NSTEP = KHW * KS;
     constexpr int R = (NSTEP % 3 == 0) ? 3 : 2;
     constexpr int D = R - 1;
@@ -209,10 +242,11 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
         aL[slot] = wc[64];
     };
 
-    issue_loads(0);
+    float stg0[MAXT][8];
+    if (NLW == 0) issue_loads(0, stg0);
 #pragma unroll
     for (int sidx = 0; sidx < D; ++sidx) load_a(0, sidx, sidx % R);
-    write_stage(0);
+    if (NLW == 0) write_stage(0, stg0);
     __syncthreads();
 
     for (int c = 0; c < g.nchunk; ++c) {
@@ -224,8 +258,8 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
             // prefetch the fragments of step + D (possibly the next chunk's first steps)
             if (step + D < NSTEP) load_a(c, step + D, (step + D) % R);
             else if (more) load_a(c + 1, step + D - NSTEP, (step + D) % R);
-            if (step == 0) {
-                if (more) issue_loads(c + 1);
+            if (NLW == 0 && step == 0) {
+                if (more) issue_loads(c + 1, stg0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             const int toff = ((tap / KW) * g.PW + (tap % KW)) * REC;
@@ -241,7 +275,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nt], 0, 0, 0);
             }
         }
-        if (more) write_stage(c + 1);
+        if (NLW == 0 && more) write_stage(c + 1, stg0);
         __syncthreads();
     }
 
@@ -250,7 +284,6 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
     // per lane the NTW tiles are added per register (= channel), then a transpose-reduce over the 32 pixel lanes of the
     // half-wave (16 -> 8 -> 4 -> 2 -> 1 registers, 16 shuffles per quantity instead of 80) leaves each channel's total in
     // one lane pair, which adds it to the fp64 workspace.  Host guarantees one sample per workgroup (NIMG == 1).
-    const bool do_stats = p.gn_ws != nullptr;
     float ssum[16], ssq[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
@@ -340,11 +373,12 @@ __global__ void __launch_bounds__(256, 2) conv_f16s_kernel(const ConvParams p, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KHW, int CK, int WM, int NTW, int MAXT>
+template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW = 0>
 static int launch_f16s(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s) {
     constexpr int REC = CK * 4 + 16;
+    constexpr int NSTAGE = NLW ? 64 * NLW : 256;
     const int nrec = g.NIMG * g.PH * g.PW;
-    if ((nrec * (CK / 8) + 255) / 256 > MAXT) {
+    if ((nrec * (CK / 8) + NSTAGE - 1) / NSTAGE > MAXT) {
         set_error("conv_f16s: staging tasks exceed MAXT");
         return CF_ERR_ARG;
     }
@@ -353,19 +387,20 @@ static int launch_f16s(const ConvParams& p, F16sGeom g, const _Float16* wpk, hip
         set_error("conv_f16s: LDS tile too large");
         return CF_ERR_ARG;
     }
-    auto kern = conv_f16s_kernel<KHW, CK, WM, NTW, MAXT>;
+    auto kern = conv_f16s_kernel<KHW, CK, WM, NTW, MAXT, NLW>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     dim3 grid((unsigned)(g.tiles_x * g.tiles_y * g.bgroups), (unsigned)((p.Cout + 32 * WM - 1) / (32 * WM)));
+    dim3 block(256 + 64 * NLW);
     const double flops = 2.0 * (double)p.B * p.Ho * p.Wo * p.Cout * (p.C1 + p.C2) * p.KH * p.KW;
     hipEvent_t e0, e1;
     if (profile_on() && profile_events(PK_CONV_F16S, flops, &e0, &e1))
-        hipExtLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, e0, e1, 0, p, g, wpk);
+        hipExtLaunchKernelGGL(kern, grid, block, lds_bytes, s, e0, e1, 0, p, g, wpk);
     else
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, s, p, g, wpk);
+        hipLaunchKernelGGL(kern, grid, block, lds_bytes, s, p, g, wpk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error(std::string("conv_f16s launch failed: ") + hipGetErrorString(e));
@@ -383,6 +418,18 @@ bool conv_f16s_supported(const ConvParams& p) {
     const long HW = (long)p.H * p.W;
     if ((long)p.B * p.C1 * HW * 4 >= (1L << 31) || (long)p.B * p.C2 * HW * 4 >= (1L << 31)) return false;  // 32-bit buffer offsets
     return true;
+}
+
+// CF_F16S_LOADERS=1 selects the wave-specialised variants (4 MFMA waves + 2-3 loader waves).  Measured (profiles/,
+// DESIGN.md 5.1): they win on stride-2 and on small maps (+10-24 %) but lose 15-25 % on the large 3x3 layers that dominate
+// the step, where the kernel is limited by bytes in flight rather than by the vmcnt coupling; default off.
+static int f16s_loader_waves() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CF_F16S_LOADERS");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
 }
 
 static int f16s_small_tile() {
@@ -449,8 +496,10 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     }
     // keep the staging work within the per-thread task budget of the variant (MAXT x 256 eight-channel tasks)
     {
-        const int maxt = s2 ? ((small && !narrow) ? 3 : 5) : (small ? 2 : 4);
-        while (g.NIMG > 1 && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 > maxt) --g.NIMG;
+        const bool ws = small && f16s_loader_waves() > 0;   // 128 staging threads instead of 256
+        const int maxt = ws ? 4 : (s2 ? ((small && !narrow) ? 3 : 5) : (small ? 2 : 4));
+        const int nstage = ws ? ((s2 && !narrow) ? 192 : 128) : 256;
+        while (g.NIMG > 1 && (g.NIMG * g.PH * g.PW * (CK / 8) + nstage - 1) / nstage > maxt) --g.NIMG;
     }
     g.tiles_x = (p.Wo + g.TW - 1) / g.TW;
     g.tiles_y = (p.Ho + g.TH - 1) / g.TH;
@@ -459,6 +508,11 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     if (one_sample_per_wg) {  // geometry probe
         *one_sample_per_wg = g.NIMG == 1;
         return CF_OK;
+    }
+    if (small && f16s_loader_waves() > 0) {
+        if (narrow && !s2) return k3 ? launch_f16s<9, 16, 1, 1, 4, 2>(p, g, wpk, s) : launch_f16s<1, 32, 1, 1, 4, 2>(p, g, wpk, s);
+        if (s2 && !narrow) return launch_f16s<9, 16, 2, 1, 4, 3>(p, g, wpk, s);
+        if (!narrow) return k3 ? launch_f16s<9, 16, 2, 2, 4, 2>(p, g, wpk, s) : launch_f16s<1, 32, 2, 2, 4, 2>(p, g, wpk, s);
     }
     if (small && narrow && !s2) return k3 ? launch_f16s<9, 16, 1, 1, 2>(p, g, wpk, s) : launch_f16s<1, 32, 1, 1, 2>(p, g, wpk, s);
     if (small && s2 && !narrow) return launch_f16s<9, 16, 2, 1, 3>(p, g, wpk, s);
