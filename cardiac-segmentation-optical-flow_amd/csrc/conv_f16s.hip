@@ -56,24 +56,25 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 // chunks of loads in flight, always one LDS buffer ahead.  vmcnt retires in issue order, so in the mixed design every
 // wait for a weight fragment also waited for the staging loads issued before it (ablating those loads made the kernel
 // 19-33 % faster); with separate roles nothing in the MFMA waves ever waits for HBM.
-template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW>
-__global__ void __launch_bounds__(256 + 64 * NLW, NLW ? 5 : ((NTW <= 2 && MAXT <= 3) ? 4 : 2))
+template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW>
+__global__ void __launch_bounds__(64 * NW + 64 * NLW, NLW ? 5 : (NW == 8 ? 2 : ((NTW <= 2 && MAXT <= 3) ? 4 : 2)))
 conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restrict__ wpk) {
     constexpr int KW = (KHW == 9) ? 3 : 1;
     constexpr int KS = CK / 16;            // MFMA k-steps per tap per chunk
     constexpr int REC = CK * 4 + 16;       // bytes per pixel record
-    constexpr int NT_WG = NTW * (4 / WM);  // n-tiles per workgroup
+    constexpr int NT_WG = NTW * (NW / WM);  // n-tiles per workgroup (NW MFMA waves = WM m-tiles x NW/WM n-tile groups)
     constexpr int NG = CK / 8;             // 8-channel groups per record
-    constexpr int NSTAGE = NLW ? 64 * NLW : 256;   // threads that stage
+    constexpr int NSTAGE = NLW ? 64 * NLW : 64 * NW;   // threads that stage
     (void)NT_WG;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const bool loader = NLW > 0 && wave >= 4;      // wave-uniform
-    const int mt = blockIdx.y * WM + (WM == 2 ? (wave & 1) : 0);  // 32-channel m-tile of this wave
-    const int ngrp = (WM == 2) ? ((wave & 3) >> 1) : (wave & 3);  // n-tile group of this wave
+    const bool loader = NLW > 0 && wave >= NW;     // wave-uniform
+    const int cw = wave % NW;                       // index among the MFMA waves
+    const int mt = blockIdx.y * WM + (cw % WM);     // 32-channel m-tile of this wave
+    const int ngrp = cw / WM;                       // n-tile group of this wave
 
     // ---- workgroup tile decode (XCD-banded so that vertically adjacent tiles share one L2)
     int bid = blockIdx.x;
@@ -106,7 +107,7 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     unsigned t_o1[MAXT], t_o2[MAXT];  // byte offsets into x1 / x2 (OOB when invalid)
     int t_lds[MAXT];                  // byte offset of the 16-byte hi slot inside a buffer, -1: no task
     unsigned t_g8[MAXT];              // (8-channel group inside the chunk) * 8
-    const int stid = NLW ? tid - 256 : tid;
+    const int stid = NLW ? tid - 64 * NW : tid;
     const bool stages = NLW ? loader : true;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
@@ -349,7 +350,7 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
         __syncthreads();
         if ((lane & 1) == 0) {
             const int r = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-            const int cl = (WM == 2 ? (wave & 1) * 32 : 0) + (r & 3) + 8 * (r >> 2) + 4 * half;  // channel inside the workgroup's block
+            const int cl = (cw % WM) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // channel inside the workgroup's block
             atomicAdd(&red[2 * cl], ssum[0]);
             atomicAdd(&red[2 * cl + 1], ssq[0]);
         }
@@ -373,10 +374,10 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW = 0>
+template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW = 0, int NW = 4>
 static int launch_f16s(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s) {
     constexpr int REC = CK * 4 + 16;
-    constexpr int NSTAGE = NLW ? 64 * NLW : 256;
+    constexpr int NSTAGE = NLW ? 64 * NLW : 64 * NW;
     const int nrec = g.NIMG * g.PH * g.PW;
     if ((nrec * (CK / 8) + NSTAGE - 1) / NSTAGE > MAXT) {
         set_error("conv_f16s: staging tasks exceed MAXT");
@@ -387,14 +388,14 @@ static int launch_f16s(const ConvParams& p, F16sGeom g, const _Float16* wpk, hip
         set_error("conv_f16s: LDS tile too large");
         return CF_ERR_ARG;
     }
-    auto kern = conv_f16s_kernel<KHW, CK, WM, NTW, MAXT, NLW>;
+    auto kern = conv_f16s_kernel<KHW, CK, WM, NTW, MAXT, NLW, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     dim3 grid((unsigned)(g.tiles_x * g.tiles_y * g.bgroups), (unsigned)((p.Cout + 32 * WM - 1) / (32 * WM)));
-    dim3 block(256 + 64 * NLW);
+    dim3 block(64 * NW + 64 * NLW);
     const double flops = 2.0 * (double)p.B * p.Ho * p.Wo * p.Cout * (p.C1 + p.C2) * p.KH * p.KW;
     hipEvent_t e0, e1;
     if (profile_on() && profile_events(PK_CONV_F16S, flops, &e0, &e1))
@@ -428,6 +429,17 @@ static int f16s_loader_waves() {
     if (v < 0) {
         const char* e = getenv("CF_F16S_LOADERS");
         v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+// CF_F16S_WIDE=0 disables the 128-channel workgroups (8 MFMA waves = 4 m-tiles x 2 n-groups) used for Cout >= 128:
+// the input patch is staged once per 128 output channels instead of once per 64.
+static int f16s_wide() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CF_F16S_WIDE");
+        v = e ? atoi(e) : 1;
     }
     return v;
 }
@@ -469,6 +481,7 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     const bool narrow = p.Cout <= 32;
     const bool small = f16s_small_tile() != 0;
     const bool s2 = k3 && p.stride == 2;
+    const bool wide = small && !s2 && f16s_wide() && p.Cout % 128 == 0 && f16s_loader_waves() == 0;
     // n-tiles (of 32 output pixels) per workgroup
     const int NT_WG = s2 ? ((small && !narrow) ? 2 : 4) : (small ? 4 : 8);
     const int npx = NT_WG * 32;
@@ -498,7 +511,7 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     {
         const bool ws = small && f16s_loader_waves() > 0;   // 128 staging threads instead of 256
         const int maxt = ws ? 4 : (s2 ? ((small && !narrow) ? 3 : 5) : (small ? 2 : 4));
-        const int nstage = ws ? ((s2 && !narrow) ? 192 : 128) : 256;
+        const int nstage = ws ? ((s2 && !narrow) ? 192 : 128) : (wide ? 512 : 256);
         while (g.NIMG > 1 && (g.NIMG * g.PH * g.PW * (CK / 8) + nstage - 1) / nstage > maxt) --g.NIMG;
     }
     g.tiles_x = (p.Wo + g.TW - 1) / g.TW;
@@ -509,6 +522,7 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
         *one_sample_per_wg = g.NIMG == 1;
         return CF_OK;
     }
+    if (wide) return k3 ? launch_f16s<9, 16, 4, 2, 2, 0, 8>(p, g, wpk, s) : launch_f16s<1, 32, 4, 2, 2, 0, 8>(p, g, wpk, s);
     if (small && f16s_loader_waves() > 0) {
         if (narrow && !s2) return k3 ? launch_f16s<9, 16, 1, 1, 4, 2>(p, g, wpk, s) : launch_f16s<1, 32, 1, 1, 4, 2>(p, g, wpk, s);
         if (s2 && !narrow) return launch_f16s<9, 16, 2, 1, 4, 3>(p, g, wpk, s);
