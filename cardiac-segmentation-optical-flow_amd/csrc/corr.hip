@@ -23,10 +23,13 @@ constexpr int CV_THREADS = 512; // waves 0-4: compute (288 lanes used), waves 5-
 constexpr int CV_STAGERS = 192;
 constexpr int CV_MAXT = 2;      // float4 staging tasks per staging thread (12*(64+8S)/4 + 64 groups <= 2*192 for S in {1,2,4})
 
+static int corr_old() { const char* e = getenv("CF_CORR_OLD"); return e ? atoi(e) : 0; }
+static int corr_dbg() { const char* e = getenv("CF_CORR_DBG"); return e ? atoi(e) : 0; }
+
 template <int S>
 __global__ void __launch_bounds__(CV_THREADS, 4) corr_volume_r4_kernel(const float* __restrict__ cur, const float* __restrict__ prev,
                                                                    float* __restrict__ out, int B, int C, int H, int W,
-                                                                   int tiles_x, int tiles_y) {
+                                                                   int tiles_x, int tiles_y, int dbg) {
     constexpr int NI = 64 / S;        // same-class pixels per tile row
     constexpr int PW = NI + 8;        // prev sub-row length (halo 4 each side)
     constexpr int PROW = S * PW;      // floats per (c, prev row) == real columns staged per row
@@ -64,29 +67,34 @@ __global__ void __launch_bounds__(CV_THREADS, 4) corr_volume_r4_kernel(const flo
     constexpr unsigned OOB = 0x80000000u;
     const int tid = threadIdx.x;
     const bool stager = tid >= 320;   // wave-uniform role split: staging registers never live in the FMA waves
-    const int st = tid - 320;
+    // Task (wave, k) is a whole wave of 64 consecutive float4 groups: wave-tasks 0..4 walk the prev groups, wave-task 5
+    // (last staging wave, k = 1) the 64 cur groups -- so the buffer descriptor of a load is wave-uniform (a per-lane choice
+    // between the two descriptors would be compiled into a waterfall loop around every load).
+    static_assert(CV_MAXT == 2 && CV_STAGERS == 192 && 12 * PGRP <= 5 * 64, "wave-task map");
+    const int swave = __builtin_amdgcn_readfirstlane((tid - 320) >> 6);   // 0..2 in the staging waves
     unsigned t_off[CV_MAXT];   // byte offset inside the sample (channel 0)
     int t_lds[CV_MAXT];        // float index inside a channel slab of the first of the 4 elements, -1: no task
-    bool t_prev[CV_MAXT];
 #pragma unroll
     for (int k = 0; k < CV_MAXT; ++k) {
-        const int grp = stager ? st + k * CV_STAGERS : NGRP;
+        const int wt = swave * 2 + k;
+        const int grp = (tid & 63) + 64 * wt;
         t_off[k] = OOB;
         t_lds[k] = -1;
-        t_prev[k] = true;
-        if (grp < 12 * PGRP) {
-            const int pr = grp / PGRP, col = (grp - pr * PGRP) * 4;   // real column offset inside the staged row
-            const int y = ytile + S * (pr - 4) + ry, x = xtile - 4 * S + col;
-            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) t_off[k] = (unsigned)(y * W + x) * 4u;
-            // de-interleave by x class: element e (0..3) of the float4 has class (col+e)%S and index (col+e)/S
-            t_lds[k] = pr * PROW + (col % S) * PW + col / S;
-        } else if (grp < NGRP) {
-            const int g2 = grp - 12 * PGRP;
+        if (!stager) continue;
+        if (wt < 5) {
+            if (grp < 12 * PGRP) {
+                const int pr = grp / PGRP, col = (grp - pr * PGRP) * 4;   // real column offset inside the staged row
+                const int y = ytile + S * (pr - 4) + ry, x = xtile - 4 * S + col;
+                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) t_off[k] = (unsigned)(y * W + x) * 4u;
+                // de-interleave by x class: element e (0..3) of the float4 has class (col+e)%S and index (col+e)/S
+                t_lds[k] = pr * PROW + (col % S) * PW + col / S;
+            }
+        } else {
+            const int g2 = grp - 5 * 64;
             const int rr = g2 >> 4, col = (g2 & 15) * 4;
             const int y = ytile + S * rr + ry, x = xtile + col;
             if (y < H && x < W) t_off[k] = (unsigned)(y * W + x) * 4u;
             t_lds[k] = PREV_C + rr * CROW + (col % S) * NI + col / S;
-            t_prev[k] = false;
         }
     }
     const long sample = (long)b * C * HW;
@@ -95,6 +103,7 @@ __global__ void __launch_bounds__(CV_THREADS, 4) corr_volume_r4_kernel(const flo
 
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const int nchunk = (C + CV_CC - 1) / CV_CC;
+    float acc[8][9];   // FMA waves only (the staging waves never touch them)
     if (stager) {
         // ---- staging waves.  Two register sets (A, B) keep the loads of TWO chunks in flight, so the wait in front of
         // each LDS write is for loads issued a whole chunk period earlier (vmcnt retires in order: waiting for the older
@@ -102,22 +111,24 @@ __global__ void __launch_bounds__(CV_THREADS, 4) corr_volume_r4_kernel(const flo
         // Same number of barriers as the FMA branch (1 + nchunk).
         f32x4 sa[CV_MAXT][CV_CC], sb[CV_MAXT][CV_CC];
         auto issue_loads = [&](int ch, f32x4 (&stg)[CV_MAXT][CV_CC]) {
+            if (dbg & 4) return;
             const int c0 = ch * CV_CC;
 #pragma unroll
             for (int k = 0; k < CV_MAXT; ++k)
 #pragma unroll
                 for (int c = 0; c < CV_CC; ++c) {
                     const unsigned off = t_off[k] + (unsigned)(c0 + c) * HW4;
-                    stg[k][c] = t_prev[k] ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_prev, off, 0, 0))
-                                          : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cur, off, 0, 0));
+                    stg[k][c] = (swave * 2 + k < 5) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_prev, off, 0, 0))
+                                                    : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cur, off, 0, 0));
                 }
         };
         auto write_stage = [&](int ch, const f32x4 (&stg)[CV_MAXT][CV_CC]) {
+            if (dbg & 4) return;
             float* base = lds + (ch & 1) * BUF;
 #pragma unroll
             for (int k = 0; k < CV_MAXT; ++k) {
                 if (t_lds[k] < 0) continue;
-                const int cls_stride = t_prev[k] ? PW : NI;
+                const int cls_stride = (swave * 2 + k < 5) ? PW : NI;
 #pragma unroll
                 for (int c = 0; c < CV_CC; ++c) {
                     float* d = base + c * SLAB + t_lds[k];
@@ -133,42 +144,40 @@ __global__ void __launch_bounds__(CV_THREADS, 4) corr_volume_r4_kernel(const flo
             }
         };
         if (S == 4) {
-            // the scalar de-interleaving LDS writes of the stride-4 variant need the registers of the second set:
-            // one chunk in flight only (no spill at 128 VGPRs)
+            // the scalar de-interleaving LDS writes of the stride-4 variant need the registers of the second set: ONE set,
+            // re-issued right after it is written out, so its loads fly while the FMA waves work on the previous chunk
             issue_loads(0, sa);
             write_stage(0, sa);
+            if (nchunk > 1) issue_loads(1, sa);
             __syncthreads();
             for (int ch = 0; ch < nchunk; ++ch) {
-                if (ch + 1 < nchunk) {
-                    issue_loads(ch + 1, sa);
-                    write_stage(ch + 1, sa);
-                }
+                if (ch + 1 < nchunk) write_stage(ch + 1, sa);
+                if (ch + 2 < nchunk) issue_loads(ch + 2, sa);
                 __syncthreads();
             }
-            return;
-        }
-        issue_loads(0, sa);
-        if (nchunk > 1) issue_loads(1, sb);
-        write_stage(0, sa);
-        __syncthreads();
-        int ch = 0;
-        while (true) {
-            // chunk ch is in LDS; set B holds chunk ch+1 (in flight); set A is free
-            if (ch + 2 < nchunk) issue_loads(ch + 2, sa);
-            if (ch + 1 < nchunk) write_stage(ch + 1, sb);
+        } else {
+            issue_loads(0, sa);
+            if (nchunk > 1) issue_loads(1, sb);
+            write_stage(0, sa);
             __syncthreads();
-            if (++ch >= nchunk) break;
-            // chunk ch is in LDS; set A holds chunk ch+1; set B is free
-            if (ch + 2 < nchunk) issue_loads(ch + 2, sb);
-            if (ch + 1 < nchunk) write_stage(ch + 1, sa);
-            __syncthreads();
-            if (++ch >= nchunk) break;
+            int ch = 0;
+            while (true) {
+                // chunk ch is in LDS; set B holds chunk ch+1 (in flight); set A is free
+                if (ch + 2 < nchunk) issue_loads(ch + 2, sa);
+                if (ch + 1 < nchunk) write_stage(ch + 1, sb);
+                __syncthreads();
+                if (++ch >= nchunk) break;
+                // chunk ch is in LDS; set A holds chunk ch+1; set B is free
+                if (ch + 2 < nchunk) issue_loads(ch + 2, sb);
+                if (ch + 1 < nchunk) write_stage(ch + 1, sa);
+                __syncthreads();
+                if (++ch >= nchunk) break;
+            }
         }
-        return;
     }
 
     // ---- FMA waves (the roles live in separate loops so that staging registers and accumulators never coexist)
-    const bool compute = tid < 288;
+    const bool compute = tid < ((dbg & 8) ? 256 : 288);
     const int dy = tid >> 5;          // 0..8  (displacement dy-4)
     const int qd = tid & 31;
     const int r = qd >> 3;            // sub-row 0..3
@@ -178,7 +187,7 @@ __global__ void __launch_bounds__(CV_THREADS, 4) corr_volume_r4_kernel(const flo
     const int prev_off = ((r + dy) * S + rx) * PW + 8 * o;       // + c*SLAB ; window [8o, 8o+16)
     const int cur_off = PREV_C + r * CROW + rx * NI + 8 * o;     // + c*SLAB
 
-    float acc[8][9];
+    if (!stager) {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -186,7 +195,7 @@ __global__ void __launch_bounds__(CV_THREADS, 4) corr_volume_r4_kernel(const flo
 
     __syncthreads();
     for (int ch = 0; ch < nchunk; ++ch) {
-        if (compute) {
+        if (compute && !(dbg & 2)) {
             const float* xb = lds + (ch & 1) * BUF;
 #pragma unroll
             for (int c = 0; c < CV_CC; ++c) {
@@ -204,18 +213,355 @@ __global__ void __launch_bounds__(CV_THREADS, 4) corr_volume_r4_kernel(const flo
         }
         __syncthreads();
     }
-    if (!compute) return;
-    const int y = ytile + S * r + ry;
-    if (y >= H) return;
+    }
+    // ---- epilogue: the 72 accumulators of a thread are 8 same-class pixels x 9 dx -- stored straight from registers
+    // every store instruction would scatter 4-B pieces over 64 sectors.  Instead the tile goes through LDS (free now) in three
+    // passes of 3 dy = 27 planes x 4 rows x 64 real columns and leaves as full 256-B row segments (float4 per lane).
+    constexpr int OROW = 72;               // padded row / plane strides keep the scalar de-interleaving writes off the same banks
+    constexpr int OPLANE = 4 * OROW + 4;
+    static_assert(27 * OPLANE <= 2 * BUF, "output staging fits in the operand buffers");
     const float invC = 1.0f / (float)C;
-    float* ob = out + (long)b * 81 * HW + (long)y * W;
+    float* ob = out + (long)b * 81 * HW;
+    for (int g = 0; g < 3; ++g) {
+        if (g) __syncthreads();            // previous pass read out
+        if (compute && dy / 3 == g && !((dbg & 1) && acc[0][0] != 12345.f)) {
+            float* o0 = lds + (dy - 3 * g) * 9 * OPLANE + r * OROW + S * 8 * o + rx;
 #pragma unroll
-    for (int d = 0; d < 9; ++d) {
-        float* oc = ob + (long)(dy * 9 + d) * HW;
+            for (int d = 0; d < 9; ++d) {
+                if (S == 1) {
+                    *reinterpret_cast<f32x4*>(o0 + d * OPLANE) = f32x4{acc[0][d] * invC, acc[1][d] * invC, acc[2][d] * invC, acc[3][d] * invC};
+                    *reinterpret_cast<f32x4*>(o0 + d * OPLANE + 4) = f32x4{acc[4][d] * invC, acc[5][d] * invC, acc[6][d] * invC, acc[7][d] * invC};
+                } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            int x = xtile + S * (8 * o + j) + rx;
-            if (x < W) oc[x] = acc[j][d] * invC;
+                    for (int j = 0; j < 8; ++j) o0[d * OPLANE + S * j] = acc[j][d] * invC;
+                }
+            }
+        }
+        __syncthreads();
+        if (dbg & 1) continue;
+        for (int i = tid; i < 27 * 64; i += CV_THREADS) {
+            const int plane = i >> 6, row = (i >> 4) & 3, c4 = i & 15;
+            const int y = ytile + S * row + ry, x = xtile + 4 * c4;
+            if (y < H && x < W)
+                *reinterpret_cast<f32x4*>(ob + (long)(27 * g + plane) * HW + (long)y * W + x) =
+                    *reinterpret_cast<const f32x4*>(lds + plane * OPLANE + row * OROW + 4 * c4);
+        }
+    }
+}
+
+// =====================================================================================================================
+// Persistent variant of the radius-4 cost volume (the default fast path).  What the profile of the kernel above showed
+// (profiles/r01_corr_ablation.md): its 4.5 FMA waves sit unevenly on the 4 SIMDs (one SIMD carries two of them and sets
+// the pace), every 4-channel chunk pays a barrier, the ds_read_b128 of the stride-4 layout run at half rate on bank
+// conflicts, and the tile epilogue is exposed.  Here:
+//   * tile = 7 sub-rows x 64 real columns of one y-class: 9 dy x 7 rows x 8 octets = 504 FMA threads = 8 full waves (two per
+//     SIMD), plus 4 staging waves (one per SIMD) -> 12 waves, ONE workgroup per CU, <=168 VGPRs;
+//   * the workgroup is persistent: it walks a band of tiles of its XCD, the staging waves stream chunk after chunk (8
+//     channels per chunk, two register sets = two chunks in flight, two LDS stages) straight across tile boundaries, so
+//     the epilogue of tile i overlaps the loads of tile i+1;
+//   * LDS rows are block-interleaved ([row][8-position block][x-class][8 floats], odd row stride in 16-B units) and the
+//     lanes of a wave are permuted so that each 16-lane ds_read_b128 group covers 2 rows x 8 octets: conflict free for
+//     every dilation;
+//   * epilogue through LDS in 9 passes (one dx each, every thread writes 8 values), double buffered: one barrier per
+//     pass, full 256-B row segments per store.
+// =====================================================================================================================
+constexpr int P7_ROWS = 7;
+constexpr int P7_CC = 8;
+constexpr int P7_FMA_THREADS = 512;
+constexpr int P7_THREADS = 768;
+constexpr int P7_OROW = 68, P7_OPLANE = P7_ROWS * P7_OROW;   // 476 = 28 (mod 64): 4 banks per (dy,row) step -> conflict-free scalar writes
+
+// Stride 4: which (prev row, 8-position block) each 8-lane group of a staging wave-task handles.  The de-interleaving writes are
+// scalar (ds_write2_b32: banks b..b+7 and b+8..b+15 per lane group); with lanes walking the groups in order they pile up to 5-deep
+// on the same banks and the FMA waves' reads starve behind them (SQ_LDS_BANK_CONFLICT 42 % of LDS cycles).  In this assignment the
+// eight 16-bank windows of every write instruction tile the 64 banks exactly twice (entry = row*4 + block, 255 = idle).
+__device__ constexpr unsigned char P7_PREV_MAP4[6][8] = {{18, 37, 48, 0, 32, 53, 38, 54},  {9, 26, 8, 50, 33, 16, 25, 34},
+                                                         {40, 58, 10, 42, 56, 46, 24, 255}, {2, 14, 52, 4, 22, 36, 49, 255},
+                                                         {20, 21, 12, 13, 6, 30, 5, 29},    {45, 57, 1, 17, 28, 44, 41, 255}};
+__device__ constexpr unsigned char P7_CUR_MAP4[2][8] = {{0, 1, 16, 17, 8, 9, 24, 25}, {4, 5, 12, 13, 20, 21, 255, 255}};
+
+template <int S>
+__global__ void __launch_bounds__(P7_THREADS, 3) corr_volume_p7_kernel(const float* __restrict__ cur, const float* __restrict__ prev,
+                                                                    float* __restrict__ out, int B, int C, int H, int W, int tiles_x,
+                                                                    int tiles_y, int ntiles, int dbg) {
+    constexpr int NI = 64 / S;                  // same-class positions per tile row
+    constexpr int NBP = (NI + 8) / 8;           // 8-position blocks per prev class row (halo 4 each side)
+    constexpr int PRS = NBP * S * 8 + 4;        // prev row stride (floats): 76 / 84 / 100 -> 19 / 21 / 25 sixteen-byte units (odd)
+    constexpr int CRS = 68;                     // cur row stride: 17 units (odd)
+    constexpr int PROWS = P7_ROWS + 8;
+    constexpr int PREV_C = PROWS * PRS;
+    constexpr int SLAB = PREV_C + P7_ROWS * CRS;   // floats per channel: [prev | cur]
+    constexpr int STAGE = P7_CC * SLAB;
+    constexpr int PGRP = (64 + 8 * S) / 4;      // float4 groups per staged prev row
+    constexpr int NPG = PROWS * PGRP;           // 270 / 300 / 360 <= 6 wave-tasks
+    constexpr int NCG = P7_ROWS * 16;           // 112 <= 2 wave-tasks
+    static_assert(NPG <= 6 * 64 && NCG <= 2 * 64, "wave-task map");
+    constexpr int OBUF = 9 * P7_OPLANE;
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE + 2 * OBUF];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+    // ---- this workgroup's tiles: XCD x (= blockIdx % 8) owns the contiguous band [ntiles*x/8, ntiles*(x+1)/8) of the tile list
+    // (x fastest, then tile row, then y-class, then sample: neighbours share halos in that XCD's L2)
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;
+    const int band_lo = (int)((long)ntiles * xcd / 8), band_hi = (int)((long)ntiles * (xcd + 1) / 8);
+    const int n_my = (band_hi - band_lo - wg + nwg - 1) / nwg;   // tiles band_lo + wg + i*nwg
+    if (band_lo + wg >= band_hi) return;
+    const int HW = H * W;
+    const unsigned HW4 = (unsigned)HW * 4u;
+    const int nchunk = (C + P7_CC - 1) / P7_CC;
+    const int nsteps = n_my * nchunk;
+    const int tid = threadIdx.x;
+    const bool stager = tid >= P7_FMA_THREADS;
+    constexpr unsigned OOB = 0x80000000u;
+
+    struct Tile { int b, ry, ytile, xtile; };
+    auto decode = [&](int i) {
+        int id = band_lo + wg + i * nwg;
+        Tile t;
+        const int tx = id % tiles_x;
+        id /= tiles_x;
+        const int ty = id % tiles_y;
+        id /= tiles_y;
+        t.ry = id % S;
+        t.b = id / S;
+        t.xtile = tx * 64;
+        t.ytile = ty * P7_ROWS;   // in class rows
+        return t;
+    };
+    // position p of class cl inside a block-interleaved row
+    auto blk = [](int p, int cl) { return ((p >> 3) * S + cl) * 8 + (p & 7); };
+
+    // FMA waves only.  Accumulators are paired along the anti-diagonal: a2[q][e] = (acc[2q][e+1], acc[2q+1][e]) -- both take the
+    // SAME prev element pv[2q+e+1], so one v_pk_fma_f32 with a = (cv[2q], cv[2q+1]) (an aligned register pair) and b = that
+    // element broadcast covers them: no shifted operand copies.  s0[q] = acc[2q][0], s8[q] = acc[2q+1][8] are the unpaired ends.
+    f32x2 a2[4][8];
+    float s0[4], s8[4];
+    if (stager) {
+        // =================================================================================================== staging waves
+        const int swave = __builtin_amdgcn_readfirstlane((tid - P7_FMA_THREADS) >> 6);   // 0..3
+        int t_lds[2];          // float index inside a channel slab of element 0 of the float4; -1: no task
+        int t_row[2], t_col[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int wt = swave * 2 + k;
+            const int grp = (tid & 63) + 64 * (wt < 6 ? wt : wt - 6);
+            t_lds[k] = -1;
+            t_row[k] = t_col[k] = 0;
+            if (S == 4) {
+                const int ent = wt < 6 ? P7_PREV_MAP4[wt][(tid & 63) >> 3] : P7_CUR_MAP4[wt - 6][(tid & 63) >> 3];
+                if (ent != 255) {
+                    const int row = ent >> 2, p = (ent & 3) * 8 + (tid & 7);   // class position; real column offset 4p
+                    t_row[k] = wt < 6 ? row - 4 : row;
+                    t_col[k] = wt < 6 ? 4 * p - 16 : 4 * p;
+                    t_lds[k] = (wt < 6 ? row * PRS : PREV_C + row * CRS) + blk(p, 0);
+                }
+            } else if (wt < 6) {
+                if (grp < NPG) {
+                    const int pr = grp / PGRP, col = (grp - pr * PGRP) * 4;   // real column offset inside the staged row
+                    t_row[k] = pr - 4;
+                    t_col[k] = col - 4 * S;
+                    t_lds[k] = pr * PRS + blk(col / S, col % S);
+                }
+            } else if (grp < NCG) {
+                const int rr = grp >> 4, col = (grp & 15) * 4;
+                t_row[k] = rr;
+                t_col[k] = col;
+                t_lds[k] = PREV_C + rr * CRS + blk(col / S, col % S);
+            }
+        }
+        // issue-side cursor (runs three steps ahead of the FMA waves)
+        int is_tile = 0, is_ch = 0;
+        unsigned t_off[2];
+        __amdgpu_buffer_rsrc_t rs_prev, rs_cur;
+        auto setup = [&]() {
+            const Tile t = decode(is_tile);
+            const long sample = (long)t.b * C * HW;
+            rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(prev + sample), 0, (int)((long)C * HW4), 0x00020000);
+            rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cur + sample), 0, (int)((long)C * HW4), 0x00020000);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int y = S * (t.ytile + t_row[k]) + t.ry, x = t.xtile + t_col[k];
+                t_off[k] = (t_lds[k] >= 0 && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? (unsigned)(y * W + x) * 4u : OOB;
+            }
+        };
+        setup();
+        f32x4 sa[2][P7_CC], sb[2][P7_CC];
+        auto issue = [&](f32x4 (&stg)[2][P7_CC]) {
+            if (is_tile >= n_my || (dbg & 4)) return;
+            const unsigned c0 = (unsigned)(is_ch * P7_CC) * HW4;
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int c = 0; c < P7_CC; ++c) {
+                    const unsigned off = t_off[k] + c0 + (unsigned)c * HW4;
+                    stg[k][c] = (swave * 2 + k < 6) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_prev, off, 0, 0))
+                                                    : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cur, off, 0, 0));
+                }
+            if (++is_ch == nchunk) {
+                is_ch = 0;
+                if (++is_tile < n_my) setup();
+            }
+        };
+        auto write = [&](int step, const f32x4 (&stg)[2][P7_CC]) {
+            if (dbg & 4) return;
+            float* base = lds + (step & 1) * STAGE;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (t_lds[k] < 0) continue;
+#pragma unroll
+                for (int c = 0; c < P7_CC; ++c) {
+                    float* d = base + c * SLAB + t_lds[k];
+                    if (S == 1) {
+                        *reinterpret_cast<f32x4*>(d) = stg[k][c];
+                    } else if (S == 2) {   // columns col..col+3 = classes 0,1,0,1 at positions p0,p0,p0+1,p0+1 (p0 even: same block)
+                        *reinterpret_cast<f32x2*>(d) = f32x2{stg[k][c][0], stg[k][c][2]};
+                        *reinterpret_cast<f32x2*>(d + 8) = f32x2{stg[k][c][1], stg[k][c][3]};
+                    } else {               // S == 4: one element per class, same position
+                        d[0] = stg[k][c][0]; d[8] = stg[k][c][1]; d[16] = stg[k][c][2]; d[24] = stg[k][c][3];
+                    }
+                }
+            }
+        };
+        auto tile_end = [&](int step) {   // the FMA waves' epilogue has 9 barriers
+            if (step % nchunk == nchunk - 1)
+                for (int d = 0; d < 9; ++d) __syncthreads();
+        };
+        issue(sa);
+        issue(sb);
+        write(0, sa);
+        issue(sa);
+        __syncthreads();
+        int step = 0;
+        while (true) {
+            // FMA waves work on `step` (stage step&1); set B holds step+1, set A step+2
+            if (step + 1 < nsteps) { write(step + 1, sb); issue(sb); }
+            __syncthreads();
+            tile_end(step);
+            if (++step >= nsteps) break;
+            if (step + 1 < nsteps) { write(step + 1, sa); issue(sa); }
+            __syncthreads();
+            tile_end(step);
+            if (++step >= nsteps) break;
+        }
+        return;
+    }
+
+    // ======================================================================================================= FMA waves
+    // lane permutation: the hardware serves a ds_read_b128 in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, +32;
+    // logical lanes 16g..16g+15 (= 2 rows x 8 octets) are mapped onto hardware group g
+    const int lane = tid & 63, lo = lane & 31;
+    const int m = lo < 4 ? lo : lo < 12 ? lo + 12 : lo < 16 ? lo - 8 : lo < 20 ? lo + 8 : lo < 28 ? lo - 12 : lo;
+    const int t = (tid & ~63) + (lane & 32) + m;
+    const bool compute = t < 9 * P7_ROWS * 8;
+    const int dy = compute ? t / (P7_ROWS * 8) : 0;   // 0..8 (displacement dy-4)
+    const int rem = t % (P7_ROWS * 8);
+    const int r = rem >> 3;                     // tile row 0..6
+    const int u = rem & 7;
+    const int rx = u % S;                       // x residue class
+    const int o = u / S;                        // octet of class positions
+    const int prev_off = (r + dy) * PRS + (o * S + rx) * 8;       // + c*SLAB ; blocks o and o+1 (the second S*8 floats further)
+    const int cur_off = PREV_C + r * CRS + (o * S + rx) * 8;      // + c*SLAB
+    const float invC = 1.0f / (float)C;
+
+    __syncthreads();
+    int step = 0;
+    for (int i = 0; i < n_my; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s0[q] = s8[q] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a2[q][e] = f32x2{0.f, 0.f};
+        }
+        for (int ch = 0; ch < nchunk; ++ch, ++step) {
+            if (compute && !(dbg & 2)) {
+                const float* xb = lds + (step & 1) * STAGE;
+                // explicit software pipeline: the operands of channel c+1 are requested before the 72 FMAs of channel c (left to
+                // itself the scheduler sinks the ds_reads next to their use and every channel pays the LDS latency: 2 waves per
+                // SIMD cannot hide it)
+                float4 pa[4], ca[2], pb[4], cb[2];
+                auto ldch = [&](int c, float4 (&pq)[4], float4 (&cq)[2]) {
+                    const float4* pp = reinterpret_cast<const float4*>(xb + c * SLAB + prev_off);
+                    const float4* cp = reinterpret_cast<const float4*>(xb + c * SLAB + cur_off);
+                    pq[0] = pp[0]; pq[1] = pp[1]; pq[2] = pp[2 * S]; pq[3] = pp[2 * S + 1];
+                    cq[0] = cp[0]; cq[1] = cp[1];
+                };
+                // One row pair q: 8 v_pk_fma_f32 (a = (cv[2q], cv[2q+1]), b = pv[2q+e+1] broadcast by op_sel) + 2 v_fmac_f32 for the ends.
+                // Written as asm so that the 40 instructions per channel stay exactly these (the scheduler otherwise re-pairs the
+                // accumulators with register copies and spills) and, with the memory clobber, so that the operand reads of the NEXT
+                // channel stay in front of them.
+                auto fmach = [&](const float4 (&pq)[4], const float4 (&cq)[2]) {
+                    const f32x2 pp[8] = {f32x2{pq[0].x, pq[0].y}, f32x2{pq[0].z, pq[0].w}, f32x2{pq[1].x, pq[1].y}, f32x2{pq[1].z, pq[1].w},
+                                         f32x2{pq[2].x, pq[2].y}, f32x2{pq[2].z, pq[2].w}, f32x2{pq[3].x, pq[3].y}, f32x2{pq[3].z, pq[3].w}};
+                    const f32x2 cv2[4] = {f32x2{cq[0].x, cq[0].y}, f32x2{cq[0].z, cq[0].w}, f32x2{cq[1].x, cq[1].y}, f32x2{cq[1].z, cq[1].w}};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        asm volatile(
+                            "v_fmac_f32_e32 %8, %18, %16\n\t"
+                            "v_pk_fma_f32 %0, %10, %11, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                            "v_pk_fma_f32 %1, %10, %12, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                            "v_pk_fma_f32 %2, %10, %12, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                            "v_pk_fma_f32 %3, %10, %13, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                            "v_pk_fma_f32 %4, %10, %13, %4 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                            "v_pk_fma_f32 %5, %10, %14, %5 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                            "v_pk_fma_f32 %6, %10, %14, %6 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                            "v_pk_fma_f32 %7, %10, %15, %7 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                            "v_fmac_f32_e32 %9, %19, %17"
+                            : "+v"(a2[q][0]), "+v"(a2[q][1]), "+v"(a2[q][2]), "+v"(a2[q][3]), "+v"(a2[q][4]), "+v"(a2[q][5]), "+v"(a2[q][6]),
+                              "+v"(a2[q][7]), "+v"(s0[q]), "+v"(s8[q])
+                            : "v"(cv2[q]), "v"(pp[q]), "v"(pp[q + 1]), "v"(pp[q + 2]), "v"(pp[q + 3]), "v"(pp[q + 4]), "v"(pp[q].x), "v"(pp[q + 4].y),
+                              "v"(cv2[q].x), "v"(cv2[q].y)
+                            : "memory");
+                    }
+                };
+                ldch(0, pa, ca);
+#pragma unroll
+                for (int c = 0; c < P7_CC; c += 2) {
+                    ldch(c + 1, pb, cb);
+                    fmach(pa, ca);
+                    if (c + 2 < P7_CC) ldch(c + 2, pa, ca);
+                    fmach(pb, cb);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- epilogue: pass d moves the dx = d-4 planes (9 dy x 7 rows x 64 columns) through LDS and out as whole row segments
+        const Tile tl = decode(i);
+        float* ob = out + (long)tl.b * 81 * HW;
+        int etid = tid;
+        asm volatile("" : "+v"(etid));   // keeps the store-phase index arithmetic out of the registers that live across the FMA loop
+#pragma unroll
+        for (int d = 0; d < 9; ++d) {
+            float* obuf = lds + 2 * STAGE + (d & 1) * OBUF;
+            if (compute) {
+                float* o0 = obuf + dy * P7_OPLANE + r * P7_OROW + S * 8 * o + rx;
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] = (d == 0 ? s0[q] : a2[q][d > 0 ? d - 1 : 0].x) * invC;
+                    v[2 * q + 1] = (d == 8 ? s8[q] : a2[q][d < 8 ? d : 0].y) * invC;
+                }
+                if (S == 1) {
+                    *reinterpret_cast<f32x4*>(o0) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(o0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o0[S * j] = v[j];
+                }
+            }
+            __syncthreads();
+            if (dbg & 1) continue;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = etid + q * P7_FMA_THREADS;
+                if (e < 9 * P7_ROWS * 16) {
+                    const int plane = e / (P7_ROWS * 16), rm = e % (P7_ROWS * 16), row = rm >> 4, c4 = rm & 15;
+                    const int y = S * (tl.ytile + row) + tl.ry, x = tl.xtile + 4 * c4;
+                    if (y < H && x < W)
+                        *reinterpret_cast<f32x4*>(ob + (long)(plane * 9 + d) * HW + (long)y * W + x) =
+                            *reinterpret_cast<const f32x4*>(obuf + plane * P7_OPLANE + row * P7_OROW + 4 * c4);
+                }
+            }
         }
     }
 }
@@ -339,15 +685,27 @@ extern "C" int cf_corr_volume(const float* cur, const float* prev, float* out, i
     hipStream_t s = as_stream(stream);
     if (radius == 4 && (stride == 1 || stride == 2 || stride == 4) && (W & 3) == 0 && (long)C * H * W * 4 < (1L << 31) &&
         ((reinterpret_cast<uintptr_t>(cur) | reinterpret_cast<uintptr_t>(prev)) & 15) == 0) {
-        int tiles_x = (W + 63) / 64, tiles_y = (H + 4 * stride - 1) / (4 * stride);
-        long nblk = (long)B * tiles_y * stride * tiles_x;
-        CF_REQUIRE(nblk < (1L << 31), "grid too large");
-        dim3 grid((unsigned)nblk), block(CV_THREADS);
         // algorithmic bytes: read cur + prev once, write the 81-channel volume once
         const double bytes = 4.0 * (double)B * H * W * (2.0 * C + 81.0);
-        if (stride == 1) launch_profiled(PK_CORRVOL_S1, bytes, corr_volume_r4_kernel<1>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y);
-        else if (stride == 2) launch_profiled(PK_CORRVOL_S2, bytes, corr_volume_r4_kernel<2>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y);
-        else launch_profiled(PK_CORRVOL_S4, bytes, corr_volume_r4_kernel<4>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y);
+        if (corr_old() || (long)(C + P7_CC) * H * W * 4 >= (1L << 31)) {
+            int tiles_x = (W + 63) / 64, tiles_y = (H + 4 * stride - 1) / (4 * stride);
+            long nblk = (long)B * tiles_y * stride * tiles_x;
+            CF_REQUIRE(nblk < (1L << 31), "grid too large");
+            dim3 grid((unsigned)nblk), block(CV_THREADS);
+            if (stride == 1) launch_profiled(PK_CORRVOL_S1, bytes, corr_volume_r4_kernel<1>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, corr_dbg());
+            else if (stride == 2) launch_profiled(PK_CORRVOL_S2, bytes, corr_volume_r4_kernel<2>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, corr_dbg());
+            else launch_profiled(PK_CORRVOL_S4, bytes, corr_volume_r4_kernel<4>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, corr_dbg());
+        } else {
+            // persistent kernel: one workgroup per CU (256 on MI355X), each walking its XCD's band of 7-row x 64-column tiles
+            const int tiles_x = (W + 63) / 64, tiles_y = ((H + stride - 1) / stride + P7_ROWS - 1) / P7_ROWS;
+            const long nt = (long)B * stride * tiles_y * tiles_x;
+            CF_REQUIRE(nt < (1L << 31), "too many tiles");
+            const unsigned nwg = (unsigned)(nt >= 256 ? 256 : ((nt + 7) / 8) * 8);
+            dim3 grid(nwg), block(P7_THREADS);
+            if (stride == 1) launch_profiled(PK_CORRVOL_S1, bytes, corr_volume_p7_kernel<1>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, (int)nt, corr_dbg());
+            else if (stride == 2) launch_profiled(PK_CORRVOL_S2, bytes, corr_volume_p7_kernel<2>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, (int)nt, corr_dbg());
+            else launch_profiled(PK_CORRVOL_S4, bytes, corr_volume_p7_kernel<4>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, (int)nt, corr_dbg());
+        }
     } else {
         long total = (long)B * (2 * radius + 1) * (2 * radius + 1) * H * W;
         hipLaunchKernelGGL(corr_volume_generic_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, s, cur, prev, out, B, C, H, W, radius,
