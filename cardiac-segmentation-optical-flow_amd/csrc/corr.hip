@@ -7,253 +7,13 @@ namespace cf {
 // =====================================================================================================================
 // Local cost volume, radius 4 (9x9 = 81 displacements), dilation s in {1,2,4}:
 //   out[b,(dy+4)*9+(dx+4),y,x] = (1/C) sum_c cur[b,c,y,x] * prev[b,c,y+dy*s,x+dx*s]      (zero outside)
-//
-// Algorithmic traffic: read cur+prev once (2*C*H*W*4 B), write 81*H*W*4 B; 2*81*C flops per pixel -> ~12-17 flop/B,
-// i.e. right at the fp32-VALU / HBM ridge of gfx950, so the inner loop must run near the VALU rate:
-//   * a dilated problem splits into independent residue classes: pixel (y,x) only meets prev pixels with the same
-//     (y mod s, x mod s).  A workgroup takes 4 sub-rows of ONE y-class x 64 real columns (all x-classes), stages the
-//     tile de-interleaved by x-class in LDS ([c][row][x-class][i]) so every thread's operands are contiguous;
-//   * thread = (dy, sub-row, 8 same-class pixels): 72 accumulators, per channel 2+4 ds_read_b128 feed 72 FMAs
-//     (12 FMA per LDS read instruction, 4.5 per loaded float) -> VALU-bound, not LDS-bound;
-//   * 9 dy x 32 (row,octet) = 288 threads (5 waves, last half-wave idle in the FMA loop, all 320 threads stage).
-// Global reads are full contiguous row segments (coalesced); writes of one wave cover whole 256-B row segments.
-// =====================================================================================================================
-constexpr int CV_CC = 4;        // channels per LDS chunk
-constexpr int CV_THREADS = 512; // waves 0-4: compute (288 lanes used), waves 5-7: staging
-constexpr int CV_STAGERS = 192;
-constexpr int CV_MAXT = 2;      // float4 staging tasks per staging thread (12*(64+8S)/4 + 64 groups <= 2*192 for S in {1,2,4})
-
-static int corr_old() { const char* e = getenv("CF_CORR_OLD"); return e ? atoi(e) : 0; }
-static int corr_dbg() { const char* e = getenv("CF_CORR_DBG"); return e ? atoi(e) : 0; }
-
-template <int S>
-__global__ void __launch_bounds__(CV_THREADS, 4) corr_volume_r4_kernel(const float* __restrict__ cur, const float* __restrict__ prev,
-                                                                   float* __restrict__ out, int B, int C, int H, int W,
-                                                                   int tiles_x, int tiles_y, int dbg) {
-    constexpr int NI = 64 / S;        // same-class pixels per tile row
-    constexpr int PW = NI + 8;        // prev sub-row length (halo 4 each side)
-    constexpr int PROW = S * PW;      // floats per (c, prev row) == real columns staged per row
-    constexpr int CROW = 64;          // floats per (c, cur row)
-    constexpr int PREV_C = 12 * PROW; // per channel
-    constexpr int CUR_C = 4 * CROW;
-    constexpr int SLAB = PREV_C + CUR_C;        // floats per channel: [prev | cur]
-    constexpr int BUF = CV_CC * SLAB;           // floats per buffer
-    constexpr int PGRP = PROW / 4;              // float4 groups per prev row
-    constexpr int NGRP = 12 * PGRP + 4 * 16;    // staging groups per channel
-    static_assert(NGRP <= CV_MAXT * CV_STAGERS, "staging tasks");
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
-
-    // ---- tile decode; blocks sharing an XCD (bid % 8) take a contiguous band of the tile list
-    const int nb = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        int xcd = bid & 7, qn = nb >> 3, rn = nb & 7;
-        bid = ((xcd < rn) ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
-    }
-    const int tx = bid % tiles_x;
-    int t = bid / tiles_x;
-    const int ry = t % S;  // y residue class
-    t /= S;
-    const int ty = t % tiles_y;
-    const int b = t / tiles_y;
-    const int xtile = tx * 64;
-    const int ytile = ty * 4 * S;
-    const int HW = H * W;
-    const unsigned HW4 = (unsigned)HW * 4u;
-
-    // ---- staging tasks: one float4 (4 consecutive real x) of one tile row, for each of the CV_CC channels of a chunk.
-    // Raw buffer loads: rows / columns outside the image park the offset at 2 GiB, channels >= C run past num_records
-    // (the descriptor covers exactly this sample's C planes) -> the range check returns 0, no branches, no masks.
-    constexpr unsigned OOB = 0x80000000u;
-    const int tid = threadIdx.x;
-    const bool stager = tid >= 320;   // wave-uniform role split: staging registers never live in the FMA waves
-    // Task (wave, k) is a whole wave of 64 consecutive float4 groups: wave-tasks 0..4 walk the prev groups, wave-task 5
-    // (last staging wave, k = 1) the 64 cur groups -- so the buffer descriptor of a load is wave-uniform (a per-lane choice
-    // between the two descriptors would be compiled into a waterfall loop around every load).
-    static_assert(CV_MAXT == 2 && CV_STAGERS == 192 && 12 * PGRP <= 5 * 64, "wave-task map");
-    const int swave = __builtin_amdgcn_readfirstlane((tid - 320) >> 6);   // 0..2 in the staging waves
-    unsigned t_off[CV_MAXT];   // byte offset inside the sample (channel 0)
-    int t_lds[CV_MAXT];        // float index inside a channel slab of the first of the 4 elements, -1: no task
-#pragma unroll
-    for (int k = 0; k < CV_MAXT; ++k) {
-        const int wt = swave * 2 + k;
-        const int grp = (tid & 63) + 64 * wt;
-        t_off[k] = OOB;
-        t_lds[k] = -1;
-        if (!stager) continue;
-        if (wt < 5) {
-            if (grp < 12 * PGRP) {
-                const int pr = grp / PGRP, col = (grp - pr * PGRP) * 4;   // real column offset inside the staged row
-                const int y = ytile + S * (pr - 4) + ry, x = xtile - 4 * S + col;
-                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) t_off[k] = (unsigned)(y * W + x) * 4u;
-                // de-interleave by x class: element e (0..3) of the float4 has class (col+e)%S and index (col+e)/S
-                t_lds[k] = pr * PROW + (col % S) * PW + col / S;
-            }
-        } else {
-            const int g2 = grp - 5 * 64;
-            const int rr = g2 >> 4, col = (g2 & 15) * 4;
-            const int y = ytile + S * rr + ry, x = xtile + col;
-            if (y < H && x < W) t_off[k] = (unsigned)(y * W + x) * 4u;
-            t_lds[k] = PREV_C + rr * CROW + (col % S) * NI + col / S;
-        }
-    }
-    const long sample = (long)b * C * HW;
-    const __amdgpu_buffer_rsrc_t rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(prev + sample), 0, (int)((long)C * HW4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_cur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(cur + sample), 0, (int)((long)C * HW4), 0x00020000);
-
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const int nchunk = (C + CV_CC - 1) / CV_CC;
-    float acc[8][9];   // FMA waves only (the staging waves never touch them)
-    if (stager) {
-        // ---- staging waves.  Two register sets (A, B) keep the loads of TWO chunks in flight, so the wait in front of
-        // each LDS write is for loads issued a whole chunk period earlier (vmcnt retires in order: waiting for the older
-        // set leaves the younger one in flight).  The loop is unrolled by two so that the sets are statically indexed.
-        // Same number of barriers as the FMA branch (1 + nchunk).
-        f32x4 sa[CV_MAXT][CV_CC], sb[CV_MAXT][CV_CC];
-        auto issue_loads = [&](int ch, f32x4 (&stg)[CV_MAXT][CV_CC]) {
-            if (dbg & 4) return;
-            const int c0 = ch * CV_CC;
-#pragma unroll
-            for (int k = 0; k < CV_MAXT; ++k)
-#pragma unroll
-                for (int c = 0; c < CV_CC; ++c) {
-                    const unsigned off = t_off[k] + (unsigned)(c0 + c) * HW4;
-                    stg[k][c] = (swave * 2 + k < 5) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_prev, off, 0, 0))
-                                                    : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cur, off, 0, 0));
-                }
-        };
-        auto write_stage = [&](int ch, const f32x4 (&stg)[CV_MAXT][CV_CC]) {
-            if (dbg & 4) return;
-            float* base = lds + (ch & 1) * BUF;
-#pragma unroll
-            for (int k = 0; k < CV_MAXT; ++k) {
-                if (t_lds[k] < 0) continue;
-                const int cls_stride = (swave * 2 + k < 5) ? PW : NI;
-#pragma unroll
-                for (int c = 0; c < CV_CC; ++c) {
-                    float* d = base + c * SLAB + t_lds[k];
-                    if (S == 1) {
-                        *reinterpret_cast<f32x4*>(d) = stg[k][c];
-                    } else if (S == 2) {  // classes 0,1,0,1 : elements (0,2) and (1,3) are neighbours inside their class rows
-                        d[0] = stg[k][c][0]; d[1] = stg[k][c][2];
-                        d[cls_stride] = stg[k][c][1]; d[cls_stride + 1] = stg[k][c][3];
-                    } else {              // S == 4: one element per class
-                        d[0] = stg[k][c][0]; d[cls_stride] = stg[k][c][1]; d[2 * cls_stride] = stg[k][c][2]; d[3 * cls_stride] = stg[k][c][3];
-                    }
-                }
-            }
-        };
-        if (S == 4) {
-            // the scalar de-interleaving LDS writes of the stride-4 variant need the registers of the second set: ONE set,
-            // re-issued right after it is written out, so its loads fly while the FMA waves work on the previous chunk
-            issue_loads(0, sa);
-            write_stage(0, sa);
-            if (nchunk > 1) issue_loads(1, sa);
-            __syncthreads();
-            for (int ch = 0; ch < nchunk; ++ch) {
-                if (ch + 1 < nchunk) write_stage(ch + 1, sa);
-                if (ch + 2 < nchunk) issue_loads(ch + 2, sa);
-                __syncthreads();
-            }
-        } else {
-            issue_loads(0, sa);
-            if (nchunk > 1) issue_loads(1, sb);
-            write_stage(0, sa);
-            __syncthreads();
-            int ch = 0;
-            while (true) {
-                // chunk ch is in LDS; set B holds chunk ch+1 (in flight); set A is free
-                if (ch + 2 < nchunk) issue_loads(ch + 2, sa);
-                if (ch + 1 < nchunk) write_stage(ch + 1, sb);
-                __syncthreads();
-                if (++ch >= nchunk) break;
-                // chunk ch is in LDS; set A holds chunk ch+1; set B is free
-                if (ch + 2 < nchunk) issue_loads(ch + 2, sb);
-                if (ch + 1 < nchunk) write_stage(ch + 1, sa);
-                __syncthreads();
-                if (++ch >= nchunk) break;
-            }
-        }
-    }
-
-    // ---- FMA waves (the roles live in separate loops so that staging registers and accumulators never coexist)
-    const bool compute = tid < ((dbg & 8) ? 256 : 288);
-    const int dy = tid >> 5;          // 0..8  (displacement dy-4)
-    const int qd = tid & 31;
-    const int r = qd >> 3;            // sub-row 0..3
-    const int u = qd & 7;
-    const int rx = u % S;             // x residue class
-    const int o = u / S;              // octet within the class row
-    const int prev_off = ((r + dy) * S + rx) * PW + 8 * o;       // + c*SLAB ; window [8o, 8o+16)
-    const int cur_off = PREV_C + r * CROW + rx * NI + 8 * o;     // + c*SLAB
-
-    if (!stager) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int d = 0; d < 9; ++d) acc[j][d] = 0.f;
-
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        if (compute && !(dbg & 2)) {
-            const float* xb = lds + (ch & 1) * BUF;
-#pragma unroll
-            for (int c = 0; c < CV_CC; ++c) {
-                const float4* pp = reinterpret_cast<const float4*>(xb + c * SLAB + prev_off);
-                const float4* cp = reinterpret_cast<const float4*>(xb + c * SLAB + cur_off);
-                float4 p0 = pp[0], p1 = pp[1], p2 = pp[2], p3 = pp[3];
-                float4 c0v = cp[0], c1v = cp[1];
-                const float pv[16] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w, p3.x, p3.y, p3.z, p3.w};
-                const float cv[8] = {c0v.x, c0v.y, c0v.z, c0v.w, c1v.x, c1v.y, c1v.z, c1v.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-#pragma unroll
-                    for (int d = 0; d < 9; ++d) acc[j][d] = fmaf(cv[j], pv[j + d], acc[j][d]);
-            }
-        }
-        __syncthreads();
-    }
-    }
-    // ---- epilogue: the 72 accumulators of a thread are 8 same-class pixels x 9 dx -- stored straight from registers
-    // every store instruction would scatter 4-B pieces over 64 sectors.  Instead the tile goes through LDS (free now) in three
-    // passes of 3 dy = 27 planes x 4 rows x 64 real columns and leaves as full 256-B row segments (float4 per lane).
-    constexpr int OROW = 72;               // padded row / plane strides keep the scalar de-interleaving writes off the same banks
-    constexpr int OPLANE = 4 * OROW + 4;
-    static_assert(27 * OPLANE <= 2 * BUF, "output staging fits in the operand buffers");
-    const float invC = 1.0f / (float)C;
-    float* ob = out + (long)b * 81 * HW;
-    for (int g = 0; g < 3; ++g) {
-        if (g) __syncthreads();            // previous pass read out
-        if (compute && dy / 3 == g && !((dbg & 1) && acc[0][0] != 12345.f)) {
-            float* o0 = lds + (dy - 3 * g) * 9 * OPLANE + r * OROW + S * 8 * o + rx;
-#pragma unroll
-            for (int d = 0; d < 9; ++d) {
-                if (S == 1) {
-                    *reinterpret_cast<f32x4*>(o0 + d * OPLANE) = f32x4{acc[0][d] * invC, acc[1][d] * invC, acc[2][d] * invC, acc[3][d] * invC};
-                    *reinterpret_cast<f32x4*>(o0 + d * OPLANE + 4) = f32x4{acc[4][d] * invC, acc[5][d] * invC, acc[6][d] * invC, acc[7][d] * invC};
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o0[d * OPLANE + S * j] = acc[j][d] * invC;
-                }
-            }
-        }
-        __syncthreads();
-        if (dbg & 1) continue;
-        for (int i = tid; i < 27 * 64; i += CV_THREADS) {
-            const int plane = i >> 6, row = (i >> 4) & 3, c4 = i & 15;
-            const int y = ytile + S * row + ry, x = xtile + 4 * c4;
-            if (y < H && x < W)
-                *reinterpret_cast<f32x4*>(ob + (long)(27 * g + plane) * HW + (long)y * W + x) =
-                    *reinterpret_cast<const f32x4*>(lds + plane * OPLANE + row * OROW + 4 * c4);
-        }
-    }
-}
-
-// =====================================================================================================================
-// Persistent variant of the radius-4 cost volume (the default fast path).  What the profile of the kernel above showed
-// (profiles/r01_corr_ablation.md): its 4.5 FMA waves sit unevenly on the 4 SIMDs (one SIMD carries two of them and sets
-// the pace), every 4-channel chunk pays a barrier, the ds_read_b128 of the stride-4 layout run at half rate on bank
-// conflicts, and the tile epilogue is exposed.  Here:
+// Algorithmic traffic: read cur+prev once (2*C*H*W*4 B), write 81*H*W*4 B; 2*81*C flops per pixel -> 12-17 flop/B, at the
+// fp32-VALU / HBM ridge of gfx950.  A dilated problem splits into independent residue classes (pixel (y,x) only meets prev
+// pixels with the same (y mod s, x mod s)); thread = (dy, tile row, 8 same-class pixels) keeps 72 accumulators and per channel
+// 6 ds_read_b128 feed 72 FMAs.  What the ablation of the first (non-persistent, 4-row-tile) version showed
+// (profiles/r01_corr_ablation.md): its 4.5 FMA waves sat unevenly on the 4 SIMDs, every 4-channel chunk paid a barrier, the
+// ds_read_b128 of the stride-4 layout ran at half rate on bank conflicts, each store instruction scattered 4-B pieces, and
+// a per-lane choice between the cur/prev descriptors was compiled into a waterfall loop around every load.  Here:
 //   * tile = 7 sub-rows x 64 real columns of one y-class: 9 dy x 7 rows x 8 octets = 504 FMA threads = 8 full waves (two per
 //     SIMD), plus 4 staging waves (one per SIMD) -> 12 waves, ONE workgroup per CU, <=168 VGPRs;
 //   * the workgroup is persistent: it walks a band of tiles of its XCD, the staging waves stream chunk after chunk (8
@@ -283,7 +43,7 @@ __device__ constexpr unsigned char P7_CUR_MAP4[2][8] = {{0, 1, 16, 17, 8, 9, 24,
 template <int S>
 __global__ void __launch_bounds__(P7_THREADS, 3) corr_volume_p7_kernel(const float* __restrict__ cur, const float* __restrict__ prev,
                                                                     float* __restrict__ out, int B, int C, int H, int W, int tiles_x,
-                                                                    int tiles_y, int ntiles, int dbg) {
+                                                                    int tiles_y, int ntiles) {
     constexpr int NI = 64 / S;                  // same-class positions per tile row
     constexpr int NBP = (NI + 8) / 8;           // 8-position blocks per prev class row (halo 4 each side)
     constexpr int PRS = NBP * S * 8 + 4;        // prev row stride (floats): 76 / 84 / 100 -> 19 / 21 / 25 sixteen-byte units (odd)
@@ -388,7 +148,7 @@ __global__ void __launch_bounds__(P7_THREADS, 3) corr_volume_p7_kernel(const flo
         setup();
         f32x4 sa[2][P7_CC], sb[2][P7_CC];
         auto issue = [&](f32x4 (&stg)[2][P7_CC]) {
-            if (is_tile >= n_my || (dbg & 4)) return;
+            if (is_tile >= n_my) return;
             const unsigned c0 = (unsigned)(is_ch * P7_CC) * HW4;
 #pragma unroll
             for (int k = 0; k < 2; ++k)
@@ -404,7 +164,6 @@ __global__ void __launch_bounds__(P7_THREADS, 3) corr_volume_p7_kernel(const flo
             }
         };
         auto write = [&](int step, const f32x4 (&stg)[2][P7_CC]) {
-            if (dbg & 4) return;
             float* base = lds + (step & 1) * STAGE;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -474,7 +233,7 @@ __global__ void __launch_bounds__(P7_THREADS, 3) corr_volume_p7_kernel(const flo
             for (int e = 0; e < 8; ++e) a2[q][e] = f32x2{0.f, 0.f};
         }
         for (int ch = 0; ch < nchunk; ++ch, ++step) {
-            if (compute && !(dbg & 2)) {
+            if (compute) {
                 const float* xb = lds + (step & 1) * STAGE;
                 // explicit software pipeline: the operands of channel c+1 are requested before the 72 FMAs of channel c (left to
                 // itself the scheduler sinks the ds_reads next to their use and every channel pays the LDS latency: 2 waves per
@@ -550,7 +309,6 @@ __global__ void __launch_bounds__(P7_THREADS, 3) corr_volume_p7_kernel(const flo
                 }
             }
             __syncthreads();
-            if (dbg & 1) continue;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int e = etid + q * P7_FMA_THREADS;
@@ -683,28 +441,20 @@ extern "C" int cf_corr_volume(const float* cur, const float* prev, float* out, i
     CF_REQUIRE(cur && prev && out, "null pointer");
     CF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && radius >= 0 && radius <= 8 && stride >= 1, "bad shape");
     hipStream_t s = as_stream(stream);
-    if (radius == 4 && (stride == 1 || stride == 2 || stride == 4) && (W & 3) == 0 && (long)C * H * W * 4 < (1L << 31) &&
+    if (radius == 4 && (stride == 1 || stride == 2 || stride == 4) && (W & 3) == 0 && (long)(C + P7_CC) * H * W * 4 < (1L << 31) &&
         ((reinterpret_cast<uintptr_t>(cur) | reinterpret_cast<uintptr_t>(prev)) & 15) == 0) {
         // algorithmic bytes: read cur + prev once, write the 81-channel volume once
         const double bytes = 4.0 * (double)B * H * W * (2.0 * C + 81.0);
-        if (corr_old() || (long)(C + P7_CC) * H * W * 4 >= (1L << 31)) {
-            int tiles_x = (W + 63) / 64, tiles_y = (H + 4 * stride - 1) / (4 * stride);
-            long nblk = (long)B * tiles_y * stride * tiles_x;
-            CF_REQUIRE(nblk < (1L << 31), "grid too large");
-            dim3 grid((unsigned)nblk), block(CV_THREADS);
-            if (stride == 1) launch_profiled(PK_CORRVOL_S1, bytes, corr_volume_r4_kernel<1>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, corr_dbg());
-            else if (stride == 2) launch_profiled(PK_CORRVOL_S2, bytes, corr_volume_r4_kernel<2>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, corr_dbg());
-            else launch_profiled(PK_CORRVOL_S4, bytes, corr_volume_r4_kernel<4>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, corr_dbg());
-        } else {
-            // persistent kernel: one workgroup per CU (256 on MI355X), each walking its XCD's band of 7-row x 64-column tiles
+        // persistent kernel: one workgroup per CU (256 on MI355X), each walking its XCD's band of 7-row x 64-column tiles
+        {
             const int tiles_x = (W + 63) / 64, tiles_y = ((H + stride - 1) / stride + P7_ROWS - 1) / P7_ROWS;
             const long nt = (long)B * stride * tiles_y * tiles_x;
             CF_REQUIRE(nt < (1L << 31), "too many tiles");
             const unsigned nwg = (unsigned)(nt >= 256 ? 256 : ((nt + 7) / 8) * 8);
             dim3 grid(nwg), block(P7_THREADS);
-            if (stride == 1) launch_profiled(PK_CORRVOL_S1, bytes, corr_volume_p7_kernel<1>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, (int)nt, corr_dbg());
-            else if (stride == 2) launch_profiled(PK_CORRVOL_S2, bytes, corr_volume_p7_kernel<2>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, (int)nt, corr_dbg());
-            else launch_profiled(PK_CORRVOL_S4, bytes, corr_volume_p7_kernel<4>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, (int)nt, corr_dbg());
+            if (stride == 1) launch_profiled(PK_CORRVOL_S1, bytes, corr_volume_p7_kernel<1>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, (int)nt);
+            else if (stride == 2) launch_profiled(PK_CORRVOL_S2, bytes, corr_volume_p7_kernel<2>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, (int)nt);
+            else launch_profiled(PK_CORRVOL_S4, bytes, corr_volume_p7_kernel<4>, grid, block, s, cur, prev, out, B, C, H, W, tiles_x, tiles_y, (int)nt);
         }
     } else {
         long total = (long)B * (2 * radius + 1) * (2 * radius + 1) * H * W;

@@ -128,7 +128,8 @@ def test_jacobian(dev, golden):
 
 # ------------------------------------------------------------------------------------------------ correlation
 @pytest.mark.parametrize("C,H,W,stride", [(16, 32, 64, 1), (24, 40, 72, 2), (8, 48, 80, 4), (64, 64, 64, 1), (12, 19, 37, 4),
-                                          (5, 7, 9, 2)])
+                                          (5, 7, 9, 2), (12, 20, 40, 4), (20, 30, 72, 1), (36, 50, 132, 2), (8, 256, 256, 4),
+                                          (3, 130, 200, 1)])
 def test_corr_volume_radius4(dev, C, H, W, stride):
     from cineflow import ops
     from oracle import ops as OO
