@@ -32,6 +32,8 @@ SIGNATURES = {
     "cf_warp_labels_2d": [P, P, P, I, I, I, I, I, P],
     "cf_memory_input": [P, P, P, P, I, I, I, P],
     "cf_jacobian_det_2d": [P, P, I, I, I, P],
+    "cf_warp_trilinear_3d": [P, P, P, I, I, I, I, I, P],
+    "cf_jacobian_det_3d": [P, P, I, I, I, I, P],
     "cf_corr_volume": [P, P, P, I, I, I, I, I, I, P],
     "cf_corr_pyramid": [P, P, P, I, I, I, I, I, P],
     "cf_corr_lookup": [P, P, P, I, I, I, I, I, P],
@@ -55,6 +57,9 @@ SIGNATURES = {
     "cf_flip2d": [P, P, I, I, I, I, I, P],
     "cf_tile_accumulate": [P, P, P, P, I, I, I, I, I, I, I, P],
     "cf_tile_finalize": [P, P, P, P, I, I, I, P],
+    "cf_tta_accumulate_3d": [P, P, I, I, I, I, I, I, I, I, F, P],
+    "cf_flip3d": [P, P, I, I, I, I, I, I, I, P],
+    "cf_tile_accumulate_3d": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cf_argmax_channels": [P, P, I, I, I, P],
     "cf_profile_enable": [I],
     "cf_profile_reset": [],

@@ -127,6 +127,56 @@ def predict_3D_2Dconv_tiled(net, x, patch_size, step_size=0.5, do_mirroring=True
     return seg.cpu().numpy(), prob.cpu().numpy()
 
 
+def mirror_and_predict_3d(net, x, mirror_axes=(0, 1, 2), do_mirroring=True, mult=None):
+    """SegmentationNetwork._internal_maybe_mirror_and_pred_3D, neural_network.py:506-571.  x [B,C,X,Y,Z] on the GPU; returns the
+    TTA-averaged softmax [B,K,X,Y,Z] (times `mult` [X,Y,Z]); up to 8 flip combinations of the axes named in `mirror_axes`."""
+    B = x.shape[0]
+    acc = torch.zeros((B, net.num_classes) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    n = 2 ** len(mirror_axes) if do_mirroring else 1
+    variants = [(0, 0, 0)]
+    if do_mirroring:
+        for m in range(1, 8):   # the reference's order: bit 0 = axis 2 (dim 4), bit 1 = axis 1, bit 2 = axis 0
+            f = (bool(m & 4), bool(m & 2), bool(m & 1))
+            if all((not f[a]) or (a in mirror_axes) for a in range(3)):
+                variants.append(tuple(int(v) for v in f))
+    for f in variants:
+        xin = x if f == (0, 0, 0) else ops.flip3d(x, *f)
+        ops.tta_accumulate_3d(net(xin), acc, f[0], f[1], f[2], 1.0 / n)
+    if mult is not None:
+        ops.mul(acc, mult, out=acc)
+    return acc
+
+
+def predict_3D_3Dconv_tiled(net, x, patch_size, step_size=0.5, do_mirroring=True, mirror_axes=(0, 1, 2), use_gaussian=True,
+                            pad_border_mode="constant", pad_kwargs=None, return_device=False):
+    """SegmentationNetwork._internal_predict_3D_3Dconv_tiled (neural_network.py:292-430).  x: numpy [C,X,Y,Z] ->
+    (seg [X,Y,Z] uint8, softmax [K,X,Y,Z] fp32).  Volume, aggregation buffers and Gaussian stay on the GPU; one 3-D patch
+    per network call as in the reference."""
+    assert x.ndim == 4, "x must be (c, x, y, z)"
+    patch_size = tuple(patch_size)
+    data, slicer = pad_nd_image(x, patch_size, pad_border_mode, pad_kwargs, True)
+    Xp, Yp, Zp = data.shape[1:]
+    steps = compute_steps_for_sliding_window(patch_size, (Xp, Yp, Zp), step_size)
+    tiles = [(lx, ly, lz) for lx in steps[0] for ly in steps[1] for lz in steps[2]]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    vol = torch.from_numpy(np.ascontiguousarray(data)).to(dev, dtype=torch.float32)  # [C,Xp,Yp,Zp]
+    K = net.num_classes
+    gauss = _gaussian_on(dev, patch_size) if (use_gaussian and len(tiles) > 1) else None
+    agg = torch.zeros((K, Xp, Yp, Zp), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((K, Xp, Yp, Zp), dtype=torch.float32, device=dev)
+    px, py, pz = patch_size
+    for (lx, ly, lz) in tiles:
+        tile = vol[None, :, lx:lx + px, ly:ly + py, lz:lz + pz].contiguous()
+        pred = mirror_and_predict_3d(net, tile, mirror_axes, do_mirroring, gauss)
+        ops.tile_accumulate_3d(pred[0], gauss, agg, cnt, lx, ly, lz)
+    seg, prob = ops.tile_finalize(agg.view(K, Xp, Yp * Zp), cnt.view(K, Xp, Yp * Zp))
+    seg = seg.view(Xp, Yp, Zp)[slicer[1], slicer[2], slicer[3]]
+    prob = prob.view(K, Xp, Yp, Zp)[:, slicer[1], slicer[2], slicer[3]]
+    if return_device:
+        return seg, prob
+    return seg.cpu().numpy(), prob.cpu().numpy()
+
+
 # ------------------------------------------------------------------------------------------------ Processor
 class Processor:
     """Crop / un-crop arithmetic of nnunet/training/network_training/processor.py:109-138, :178-186, :223-230.

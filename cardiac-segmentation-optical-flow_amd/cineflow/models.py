@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .nn import (Module, conv_norm, Conv2d, ConvTranspose2d, GroupNorm, ConvBlocks2DGroupLegacy, Encoder2D, Decoder2D, CrossAttentionLayer,
+from .nn import (Module, conv_norm, Conv2d, ConvTranspose2d, GroupNorm, Conv3d, ConvTranspose3d, InstanceNorm3d, ConvBlocks2DGroupLegacy, Encoder2D, Decoder2D, CrossAttentionLayer,
                  TransformerFlowEncoderSuccessiveNoEmb, ConvGRUCell, SpatialTransformer, VecInt)
 
 
@@ -448,3 +448,71 @@ class Generic_UNet(Module):
             blk = self.conv_blocks_localization[u]
             x = blk[1](blk[0](up, x2=skips[-(u + 1)]))
         return self.seg_outputs[-1](x)
+
+
+# ------------------------------------------------------------------------------------------------ Generic_UNet (3D)
+class ConvDropoutNormNonlin3D(Module):
+    """generic_UNet.py:26-69 with conv_op = nn.Conv3d: conv -> InstanceNorm3d(affine) -> LeakyReLU(0.01)."""
+
+    def __init__(self, cin, cout, kernel=(3, 3, 3), stride=(1, 1, 1)):
+        super().__init__()
+        self.conv = Conv3d(cin, cout, kernel, stride, bias=True)
+        self.instnorm = InstanceNorm3d(cout)
+
+    def forward(self, x, x2=None):
+        return self.instnorm(self.conv(x, x2=x2), act="lrelu")
+
+
+class StackedConvLayers3D(Module):
+    """generic_UNet.py:79-144."""
+
+    def __init__(self, cin, cout, num_convs, kernel, first_stride=None):
+        super().__init__()
+        self.input_channels, self.output_channels = cin, cout
+        self.blocks = [ConvDropoutNormNonlin3D(cin, cout, kernel, first_stride if first_stride is not None else (1, 1, 1))] + \
+                      [ConvDropoutNormNonlin3D(cout, cout, kernel) for _ in range(num_convs - 1)]
+
+    def forward(self, x, x2=None):
+        for i, b in enumerate(self.blocks):
+            x = b(x, x2=x2) if i == 0 else b(x)
+        return x
+
+
+class Generic_UNet3D(Generic_UNet):
+    """generic_UNet.py:167-408 with conv_op = nn.Conv3d -- the network `_internal_predict_3D_3Dconv_tiled` drives
+    (neural_network.py:292-430): per-stage pool_op_kernel_sizes / conv_kernel_sizes from the plans (anisotropic (1,2,2) /
+    (1,3,3) stages allowed), convolutional pooling and upsampling, MAX_NUM_FILTERS_3D = 320.  Same state_dict keys as the
+    reference.  forward: [B,C,D,H,W] -> full-resolution logits [B,K,D,H,W]."""
+
+    MAX_NUM_FILTERS_3D = 320
+
+    def __init__(self, input_channels, base_num_features, num_classes, num_pool, num_conv_per_stage=2, pool_op_kernel_sizes=None,
+                 conv_kernel_sizes=None):
+        Module.__init__(self)
+        self.num_classes = num_classes
+        self.input_channels = input_channels
+        pool = [tuple(p) for p in (pool_op_kernel_sizes or [(2, 2, 2)] * num_pool)]
+        kern = [tuple(k) for k in (conv_kernel_sizes or [(3, 3, 3)] * (num_pool + 1))]
+        self.pool_op_kernel_sizes, self.conv_kernel_sizes = pool, kern
+        ctx, loc, tu, seg = [], [], [], []
+        out_f, in_f = base_num_features, input_channels
+        for d in range(num_pool):
+            ctx.append(StackedConvLayers3D(in_f, out_f, num_conv_per_stage, kern[d], pool[d - 1] if d != 0 else None))
+            in_f = out_f
+            out_f = min(int(np.round(out_f * 2)), self.MAX_NUM_FILTERS_3D)
+        final = out_f
+        ctx.append({0: StackedConvLayers3D(in_f, out_f, num_conv_per_stage - 1, kern[num_pool], pool[-1]),
+                    1: StackedConvLayers3D(out_f, final, 1, kern[num_pool])})
+        skip_ch = [c.output_channels for c in ctx[:-1]]
+        for u in range(num_pool):
+            from_down = final
+            from_skip = skip_ch[-(1 + u)]
+            final = from_skip
+            tu.append(ConvTranspose3d(from_down, from_skip, pool[-(u + 1)], bias=False))
+            loc.append({0: StackedConvLayers3D(from_skip * 2, from_skip, num_conv_per_stage - 1, kern[-(u + 1)]),
+                        1: StackedConvLayers3D(from_skip, final, 1, kern[-(u + 1)])})
+            seg.append(Conv3d(final, num_classes, (1, 1, 1), bias=False))
+        self.conv_blocks_localization = loc
+        self.conv_blocks_context = ctx
+        self.tu = tu
+        self.seg_outputs = seg

@@ -165,6 +165,116 @@ class LayerNormCF(Module):
         return ops.layer_norm_cf(x, self._p["weight"], self._p["bias"], self.eps, out=x if inplace else None)
 
 
+
+# --------------------------------------------------------------------------------------------- 3-D layers (composition)
+class Conv3d(Module):
+    """nn.Conv3d for the 3-D U-Net behind _internal_predict_3D_3Dconv_tiled (generic_UNet.py with conv_op = nn.Conv3d).
+    A (kd, k, k) convolution is the sum over the kd depth taps of 2-D (k, k) convolutions of depth-shifted planes, so it
+    runs on the same MFMA implicit-GEMM kernels: the volume is re-laid as [B, D, C, H, W] planes, the centre tap writes
+    every output plane (with the bias), the other taps accumulate through the kernel's residual input.  Kernel sizes 1 or 3
+    per axis (padding 1 for 3, as generic_UNet.py:252-254), strides 1 or 2, equal in H and W.  Input/output NCDHW."""
+
+    def __init__(self, cin, cout, kernel_size=(3, 3, 3), stride=(1, 1, 1), bias=True):
+        super().__init__()
+        self.cin, self.cout, self.ks, self.stride = cin, cout, tuple(kernel_size), tuple(stride)
+        assert all(k in (1, 3) for k in self.ks) and self.ks[1] == self.ks[2], "kernel sizes 1 or 3, equal in-plane"
+        assert all(st in (1, 2) for st in self.stride) and self.stride[1] == self.stride[2], "strides 1 or 2, equal in-plane"
+        self._param("weight", (cout, cin) + self.ks)
+        if bias:
+            self._param("bias", (cout,))
+
+    def _prepare(self):
+        if "weight" not in self._p:
+            return
+        k, pad = self.ks[1], (self.ks[1] // 2, self.ks[1] // 2)
+        self._f16s = ops.f16s_supported(k, k, self.stride[1], pad)
+        self._taps = []
+        for dz in range(self.ks[0]):
+            w2 = self._p["weight"][:, :, dz].contiguous()
+            self._taps.append((ops.prep_conv_weight(w2), ops.pack_conv_weight_f16s(w2) if self._f16s else None))
+
+    def _conv2d(self, dz, x, x2, bias, res, out):
+        k, st, pad = self.ks[1], self.stride[1], (self.ks[1] // 2, self.ks[1] // 2)
+        wt, pk = self._taps[dz]
+        if self._f16s and ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, x2, k):
+            return ops.conv2d_f16s(x, pk[0], pk[1], bias, self.cout, k, k, st, pad, x2=x2, res=res, out=out)
+        return ops.conv2d(x, wt, bias, self.cout, k, k, st, pad, x2=x2, res=res, out=out)
+
+    def forward(self, x, x2=None):
+        B, _, D, H, W = x.shape
+        kd, sd, pd = self.ks[0], self.stride[0], self.ks[0] // 2
+        k, st = self.ks[1], self.stride[1]
+        Do = (D + 2 * pd - kd) // sd + 1
+        Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
+        xp = x.permute(0, 2, 1, 3, 4).contiguous()
+        x2p = None if x2 is None else x2.permute(0, 2, 1, 3, 4).contiguous()
+        outp = torch.empty((B, Do, self.cout, Ho, Wo), dtype=torch.float32, device=x.device)
+        bias = self._p.get("bias")
+        order = [pd] + [dz for dz in range(kd) if dz != pd]          # centre tap first: it reaches every output plane
+        for b in range(B):
+            for n, dz in enumerate(order):
+                zo_lo = max(0, -((dz - pd) // sd))                   # smallest zo with zo*sd + dz - pd >= 0
+                zo_hi = min(Do - 1, (D - 1 - dz + pd) // sd)
+                if zo_hi < zo_lo:
+                    continue
+                zi_lo = zo_lo * sd + dz - pd
+                sl = slice(zi_lo, zi_lo + (zo_hi - zo_lo) * sd + 1, sd)
+                xin = xp[b, sl] if sd == 1 else xp[b, sl].contiguous()
+                xin2 = None if x2p is None else (x2p[b, sl] if sd == 1 else x2p[b, sl].contiguous())
+                osl = outp[b, zo_lo:zo_hi + 1]
+                self._conv2d(dz, xin, xin2, bias if n == 0 else None, None if n == 0 else osl, osl)
+        return outp.permute(0, 2, 1, 3, 4).contiguous()
+
+
+class ConvTranspose3d(Module):
+    """nn.ConvTranspose3d(kernel = stride = (kd, 2, 2), kd in {1, 2}, no overlap): output plane kd*z + dz is the 2-D transposed
+    convolution of input plane z with the depth tap dz (generic_UNet.py:343-344 with the plans' pool_op_kernel_sizes)."""
+
+    def __init__(self, cin, cout, kernel_size=(2, 2, 2), bias=False):
+        super().__init__()
+        self.cin, self.cout, self.ks = cin, cout, tuple(kernel_size)
+        assert self.ks[0] in (1, 2) and self.ks[1:] == (2, 2), "transposed kernel (1|2, 2, 2)"
+        self._param("weight", (cin, cout) + self.ks)
+        if bias:
+            self._param("bias", (cout,))
+
+    def _prepare(self):
+        if "weight" in self._p:
+            self._taps = []
+            for dz in range(self.ks[0]):
+                w2 = self._p["weight"][:, :, dz].contiguous()    # [Cin,Cout,2,2]
+                self._taps.append((w2, ops.pack_conv_weight_f16s(w2.permute(1, 2, 3, 0).reshape(self.cout * 4, self.cin, 1, 1))))
+
+    def forward(self, x):
+        B, C, D, H, W = x.shape
+        kd = self.ks[0]
+        xp = x.permute(0, 2, 1, 3, 4).contiguous().view(B * D, C, H, W)
+        outp = torch.empty((B, D, kd, self.cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+        for dz in range(kd):
+            w2, pk = self._taps[dz]
+            if ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(xp, None, 1):
+                y = ops.conv_transpose2d_k2s2_f16s(xp, pk[0], pk[1], self._p.get("bias"), self.cout)
+            else:
+                y = ops.conv_transpose2d_k2s2(xp, w2, self._p.get("bias"))
+            outp[:, :, dz] = y.view(B, D, self.cout, 2 * H, 2 * W)
+        return outp.view(B, D * kd, self.cout, 2 * H, 2 * W).permute(0, 2, 1, 3, 4).contiguous()
+
+
+class InstanceNorm3d(Module):
+    """nn.InstanceNorm3d(C, affine=True) fused with the following LeakyReLU: statistics over (D, H, W) per (sample, channel) --
+    the NCDHW tensor viewed as [B, C, D*H, W] on the GroupNorm kernels with groups = C."""
+
+    def __init__(self, channels, eps=1e-5):
+        super().__init__()
+        self.channels, self.eps = channels, eps
+        self._param("weight", (channels,))
+        self._param("bias", (channels,))
+
+    def forward(self, x, act=None):
+        B, C, D, H, W = x.shape
+        y = ops.group_norm(x.view(B, C, D * H, W), self._p["weight"], self._p["bias"], C, self.eps, act=act, out=x.view(B, C, D * H, W))
+        return y.view(B, C, D, H, W)
+
 # --------------------------------------------------------------------------------------------- lib/utils.py blocks
 class DoubleConv(Module):
     """nnunet/lib/utils.py:1182-1215: GELU(GN(conv)) twice, residual (optionally 1x1 conv + GN) added after the
@@ -485,8 +595,8 @@ class ConvGRUCell(Module):
 
 
 class SpatialTransformer(Module):
-    """nnunet/network_architecture/integration.py:37-79 (2-D).  Keeps the reference's persistent `grid` buffer
-    key so checkpoints load, but the kernel never reads it."""
+    """nnunet/network_architecture/integration.py:37-79 (2-D and the 3-D branch :75-77, chosen by len(size)).  Keeps the
+    reference's persistent `grid` buffer key so checkpoints load, but the kernel never reads it."""
 
     def __init__(self, size, mode="bilinear"):
         super().__init__()

@@ -39,6 +39,13 @@ def _opt(t, name="tensor"):
 
 # ------------------------------------------------------------------------------------------------ warp family
 def warp_bilinear(flow, src):
+    """SpatialTransformer.forward: flow [B,2,H,W] / src [B,C,H,W], or the 3-D branch flow [B,3,D,H,W] / src [B,C,D,H,W]."""
+    if src.dim() == 5:
+        B, C, D, H, W = src.shape
+        assert flow.shape == (B, 3, D, H, W), (flow.shape, src.shape)
+        out = torch.empty_like(src)
+        check(lib().cf_warp_trilinear_3d(_f32(flow), _f32(src), _f32(out), B, C, D, H, W, _stream()), "cf_warp_trilinear_3d")
+        return out
     B, C, H, W = src.shape
     assert flow.shape == (B, 2, H, W), (flow.shape, src.shape)
     out = torch.empty_like(src)
@@ -47,6 +54,12 @@ def warp_bilinear(flow, src):
 
 
 def vecint(vec, nsteps=7):
+    if vec.dim() == 5:   # 3-D fields: the same scaling and squaring, one warp launch per step
+        assert vec.shape[1] == 3
+        v = mul(vec, torch.full((1,), 1.0 / (2 ** nsteps), dtype=torch.float32, device=vec.device))
+        for _ in range(nsteps):
+            v = add(v, warp_bilinear(v, v))
+        return v
     B, two, H, W = vec.shape
     assert two == 2
     out = torch.empty_like(vec)
@@ -73,7 +86,13 @@ def memory_input(x0, xt, cum):
 
 
 def jacobian_det(disp):
-    """disp [B,2,H,W] float32 -> float64 [B,H,W]."""
+    """disp [B,2,H,W] float32 -> float64 [B,H,W]; or the 3-D case disp [B,3,D,H,W] -> float64 [B,D,H,W]."""
+    if disp.dim() == 5:
+        B, three, D, H, W = disp.shape
+        assert three == 3
+        out = torch.empty((B, D, H, W), dtype=torch.float64, device=disp.device)
+        check(lib().cf_jacobian_det_3d(_f32(disp), out.data_ptr(), B, D, H, W, _stream()), "cf_jacobian_det_3d")
+        return out
     B, two, H, W = disp.shape
     assert two == 2
     out = torch.empty((B, H, W), dtype=torch.float64, device=disp.device)
@@ -406,6 +425,29 @@ def tile_finalize(agg, cnt):
     seg = torch.empty((X, Y), dtype=torch.uint8, device=agg.device)
     check(lib().cf_tile_finalize(_f32(agg), _f32(cnt), _f32(probs), _u8(seg), K, X, Y, _stream()), "cf_tile_finalize")
     return seg, probs
+
+
+def tta_accumulate_3d(logits, acc, flip_d, flip_h, flip_w, weight):
+    B, K, D, H, W = logits.shape
+    assert acc.shape == logits.shape
+    check(lib().cf_tta_accumulate_3d(_f32(logits), _f32(acc), B, K, D, H, W, int(flip_d), int(flip_h), int(flip_w), float(weight),
+                                     _stream()), "cf_tta_accumulate_3d")
+    return acc
+
+
+def flip3d(src, flip_d, flip_h, flip_w):
+    D, H, W = src.shape[-3:]
+    N = src.numel() // (D * H * W)
+    dst = torch.empty_like(src)
+    check(lib().cf_flip3d(_f32(src), _f32(dst), N, D, H, W, int(flip_d), int(flip_h), int(flip_w), _stream()), "cf_flip3d")
+    return dst
+
+
+def tile_accumulate_3d(pred, gauss, agg, cnt, lx, ly, lz):
+    K, px, py, pz = pred.shape
+    _, X, Y, Z = agg.shape
+    check(lib().cf_tile_accumulate_3d(_f32(pred), _opt(gauss), _f32(agg), _f32(cnt), K, X, Y, Z, lx, ly, lz, px, py, pz, _stream()),
+          "cf_tile_accumulate_3d")
 
 
 def argmax_channels(x):

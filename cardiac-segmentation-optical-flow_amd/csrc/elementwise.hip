@@ -123,6 +123,53 @@ __global__ void __launch_bounds__(256) tile_accumulate_kernel(const float* __res
     }
 }
 
+
+// ---- 3-D twins for _internal_maybe_mirror_and_pred_3D / _internal_predict_3D_3Dconv_tiled (neural_network.py:506-571, :292-430)
+__global__ void __launch_bounds__(256) tta_accumulate_3d_kernel(const float* __restrict__ logits, float* __restrict__ acc, int K, int D,
+                                                               int H, int W, int fd, int fh, int fw, float weight, long total) {
+    const long HW = (long)H * W, V = (long)D * HW;
+    GRID_STRIDE(i, total) {  // i over (b, z, y, x)
+        long p = i % V, b = i / V;
+        int z = (int)(p / HW), q = (int)(p - (long)z * HW);
+        int y = q / W, x = q - y * W;
+        int zs = fd ? D - 1 - z : z, ys = fh ? H - 1 - y : y, xs = fw ? W - 1 - x : x;
+        const float* lp = logits + b * K * V + (long)zs * HW + (long)ys * W + xs;
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, lp[k * V]);
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += expf(lp[k * V] - mx);
+        float* ap = acc + b * K * V + p;
+        for (int k = 0; k < K; ++k) ap[k * V] += weight * (expf(lp[k * V] - mx) / sum);
+    }
+}
+
+__global__ void __launch_bounds__(256) flip3d_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int H, int W, int fd,
+                                                    int fh, int fw, long total) {
+    const long HW = (long)H * W, V = (long)D * HW;
+    GRID_STRIDE(i, total) {
+        long p = i % V, n = i / V;
+        int z = (int)(p / HW), q = (int)(p - (long)z * HW);
+        int y = q / W, x = q - y * W;
+        dst[i] = src[n * V + (long)(fd ? D - 1 - z : z) * HW + (long)(fh ? H - 1 - y : y) * W + (fw ? W - 1 - x : x)];
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_accumulate_3d_kernel(const float* __restrict__ pred, const float* __restrict__ gauss,
+                                                                float* __restrict__ agg, float* __restrict__ cnt, int X, int Y, int Z,
+                                                                int lx, int ly, int lz, int px, int py, int pz, long total) {
+    const long pv = (long)px * py * pz;
+    GRID_STRIDE(i, total) {  // i over (k, tx, ty, tz)
+        long t = i % pv, k = i / pv;
+        int tz = (int)(t % pz);
+        long r = t / pz;
+        int ty = (int)(r % py), tx = (int)(r / py);
+        float g = gauss ? gauss[t] : 1.f;
+        long o = ((k * X + lx + tx) * Y + ly + ty) * Z + lz + tz;
+        agg[o] += pred[i];  // pred already carries the Gaussian weight (mult in _internal_maybe_mirror_and_pred_3D)
+        cnt[o] += g;
+    }
+}
+
 __global__ void __launch_bounds__(256) tile_finalize_kernel(const float* __restrict__ agg, const float* __restrict__ cnt,
                                                            float* __restrict__ probs, uint8_t* __restrict__ seg, int K, long XY) {
     GRID_STRIDE(i, XY) {
@@ -248,4 +295,28 @@ extern "C" int cf_argmax_channels(const float* x, uint8_t* out, int B, int K, in
     CF_REQUIRE(B > 0 && K > 0 && K <= 255 && HW > 0, "bad shape");
     long total = (long)B * HW;
     LAUNCH_FLAT(argmax_channels_kernel, total, x, out, K, (long)HW, total);
+}
+
+extern "C" int cf_tta_accumulate_3d(const float* logits, float* acc, int B, int K, int D, int H, int W, int flip_d, int flip_h, int flip_w,
+                                    float weight, void* stream) {
+    CF_REQUIRE(logits && acc, "null pointer");
+    CF_REQUIRE(B > 0 && K > 0 && D > 0 && H > 0 && W > 0, "bad shape");
+    long total = (long)B * D * H * W;
+    LAUNCH_FLAT(tta_accumulate_3d_kernel, total, logits, acc, K, D, H, W, flip_d, flip_h, flip_w, weight, total);
+}
+
+extern "C" int cf_flip3d(const float* src, float* dst, int N, int D, int H, int W, int flip_d, int flip_h, int flip_w, void* stream) {
+    CF_REQUIRE(src && dst && src != dst, "null or aliased pointer");
+    CF_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "bad shape");
+    long total = (long)N * D * H * W;
+    LAUNCH_FLAT(flip3d_kernel, total, src, dst, D, H, W, flip_d, flip_h, flip_w, total);
+}
+
+extern "C" int cf_tile_accumulate_3d(const float* pred, const float* gauss, float* agg, float* cnt, int K, int X, int Y, int Z, int lx,
+                                     int ly, int lz, int px, int py, int pz, void* stream) {
+    CF_REQUIRE(pred && agg && cnt, "null pointer");
+    CF_REQUIRE(K > 0 && lx >= 0 && ly >= 0 && lz >= 0 && lx + px <= X && ly + py <= Y && lz + pz <= Z && px > 0 && py > 0 && pz > 0,
+               "tile out of range");
+    long total = (long)K * px * py * pz;
+    LAUNCH_FLAT(tile_accumulate_3d_kernel, total, pred, gauss, agg, cnt, X, Y, Z, lx, ly, lz, px, py, pz, total);
 }

@@ -113,6 +113,91 @@ __global__ void __launch_bounds__(256) jacobian_det_2d_kernel(const float* __res
     }
 }
 
+
+// 3-D branch of SpatialTransformer (integration.py:75-77): trilinear, align_corners=True, zeros outside.  Weights and the
+// accumulation order follow ATen's scalar grid_sampler_3d ((x1 - ix) * (y1 - iy) * (z1 - iz), corners tnw, tne, tsw, tse,
+// bnw, bne, bsw, bse).  flow channel i displaces along axis i of (D, H, W).
+__global__ void __launch_bounds__(256) warp_trilinear_3d_kernel(const float* __restrict__ flow, const float* __restrict__ src,
+                                                                float* __restrict__ out, int B, int C, int D, int H, int W) {
+    const long HW = (long)H * W, V = (long)D * HW;
+    const long total = (long)B * V;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / V);
+        const long p = idx - (long)b * V;
+        const int z = (int)(p / HW);
+        const int q = (int)(p - (long)z * HW);
+        const int y = q / W, x = q - y * W;
+        const float* fb = flow + (long)b * 3 * V + p;
+        const float iz = st_coord((float)z, fb[0], (float)(D - 1));
+        const float iy = st_coord((float)y, fb[V], (float)(H - 1));
+        const float ix = st_coord((float)x, fb[2 * V], (float)(W - 1));
+        float zf = floorf(iz), yf = floorf(iy), xf = floorf(ix);
+        // weights before the clamp (the clamp only guards the float->int conversion of far-away / NaN coordinates)
+        const float wz1 = __fsub_rn(__fadd_rn(zf, 1.0f), iz), wz0 = __fsub_rn(iz, zf);
+        const float wy1 = __fsub_rn(__fadd_rn(yf, 1.0f), iy), wy0 = __fsub_rn(iy, yf);
+        const float wx1 = __fsub_rn(__fadd_rn(xf, 1.0f), ix), wx0 = __fsub_rn(ix, xf);
+        zf = fminf(fmaxf(zf, -2.0f), (float)D + 1.0f);
+        yf = fminf(fmaxf(yf, -2.0f), (float)H + 1.0f);
+        xf = fminf(fmaxf(xf, -2.0f), (float)W + 1.0f);
+        const int z0 = (int)zf, y0 = (int)yf, x0 = (int)xf;
+        const bool zv0 = z0 >= 0 && z0 < D, zv1 = z0 + 1 >= 0 && z0 + 1 < D;
+        const bool yv0 = y0 >= 0 && y0 < H, yv1 = y0 + 1 >= 0 && y0 + 1 < H;
+        const bool xv0 = x0 >= 0 && x0 < W, xv1 = x0 + 1 >= 0 && x0 + 1 < W;
+        float w[8];
+        bool v[8];
+        long off[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {   // k = dz*4 + dy*2 + dx : tnw, tne, tsw, tse, bnw, bne, bsw, bse
+            const int dz = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+            w[k] = __fmul_rn(__fmul_rn(dx ? wx0 : wx1, dy ? wy0 : wy1), dz ? wz0 : wz1);
+            v[k] = (dz ? zv1 : zv0) && (dy ? yv1 : yv0) && (dx ? xv1 : xv0);
+            off[k] = (long)(z0 + dz) * HW + (long)(y0 + dy) * W + (x0 + dx);
+        }
+        for (int c = 0; c < C; ++c) {
+            const float* sp = src + ((long)b * C + c) * V;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (v[k]) acc = __fadd_rn(acc, __fmul_rn(sp[off[k]], w[k]));
+            out[((long)b * C + c) * V + p] = acc;
+        }
+    }
+}
+
+// 3-D variant of compute_jacobian.py:42-52 (np.gradient in float64; displacement channel i along axis i of (D, H, W))
+__global__ void __launch_bounds__(256) jacobian_det_3d_kernel(const float* __restrict__ disp, double* __restrict__ det, int B, int D,
+                                                              int H, int W) {
+    const long HW = (long)H * W, V = (long)D * HW;
+    const long total = (long)B * V;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / V);
+        const long p = idx - (long)b * V;
+        const int i = (int)(p / HW);
+        const int q = (int)(p - (long)i * HW);
+        const int j = q / W, k = q - j * W;
+        const float* d = disp + (long)b * 3 * V;
+        const int lo[3] = {i > 0 ? i - 1 : i, j > 0 ? j - 1 : j, k > 0 ? k - 1 : k};
+        const int hi[3] = {i < D - 1 ? i + 1 : i, j < H - 1 ? j + 1 : j, k < W - 1 ? k + 1 : k};
+        const int pos[3] = {i, j, k};
+        double g[3][3];   // g[axis][component] = d(phi_component)/d(axis)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int ph[3] = {i, j, k}, pl[3] = {i, j, k};
+            ph[a] = hi[a];
+            pl[a] = lo[a];
+            const long oh = (long)ph[0] * HW + (long)ph[1] * W + ph[2], ol = (long)pl[0] * HW + (long)pl[1] * W + pl[2];
+            const double h = (double)(hi[a] - lo[a]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                g[a][c] = (((double)d[c * V + oh] + (c == a ? ph[a] : pos[c])) - ((double)d[c * V + ol] + (c == a ? pl[a] : pos[c]))) / h;
+        }
+        const double d0 = g[0][0] * (g[1][1] * g[2][2] - g[1][2] * g[2][1]);
+        const double d1 = g[0][1] * (g[1][0] * g[2][2] - g[1][2] * g[2][0]);
+        const double d2 = g[0][2] * (g[1][0] * g[2][1] - g[1][1] * g[2][0]);
+        det[idx] = d0 - d1 + d2;
+    }
+}
+
 }  // namespace cf
 
 using namespace cf;
@@ -174,6 +259,25 @@ extern "C" int cf_jacobian_det_2d(const float* disp, double* det, int B, int H, 
     CF_REQUIRE(B > 0 && H >= 2 && W >= 2, "bad shape");
     long n = (long)B * H * W;
     hipLaunchKernelGGL(jacobian_det_2d_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, as_stream(stream), disp, det, B, H, W);
+    CF_CHECK_LAUNCH();
+    return CF_OK;
+}
+
+extern "C" int cf_warp_trilinear_3d(const float* flow, const float* src, float* out, int B, int C, int D, int H, int W, void* stream) {
+    CF_REQUIRE(flow && src && out, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && D > 1 && H > 1 && W > 1, "bad shape B=%d C=%d D=%d H=%d W=%d", B, C, D, H, W);
+    CF_REQUIRE(out != src, "out must not alias src");
+    long n = (long)B * D * H * W;
+    hipLaunchKernelGGL(warp_trilinear_3d_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, as_stream(stream), flow, src, out, B, C, D, H, W);
+    CF_CHECK_LAUNCH();
+    return CF_OK;
+}
+
+extern "C" int cf_jacobian_det_3d(const float* disp, double* det, int B, int D, int H, int W, void* stream) {
+    CF_REQUIRE(disp && det, "null pointer");
+    CF_REQUIRE(B > 0 && D >= 2 && H >= 2 && W >= 2, "bad shape");
+    long n = (long)B * D * H * W;
+    hipLaunchKernelGGL(jacobian_det_3d_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, as_stream(stream), disp, det, B, D, H, W);
     CF_CHECK_LAUNCH();
     return CF_OK;
 }

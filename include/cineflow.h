@@ -68,6 +68,13 @@ int cf_memory_input(const float* x0, const float* xt, const float* cum, float* o
  * disp [B,2,H,W] channel-first (channel 0 along axis H); det float64 [B,H,W].  H,W >= 2. */
 int cf_jacobian_det_2d(const float* disp, double* det, int B, int H, int W, void* stream);
 
+/* 3-D branches of the same two functions: SpatialTransformer.forward for a volume (integration.py:75-77; trilinear,
+ * align_corners=True, zeros outside; flow [B,3,D,H,W] with channel i displacing along axis i of (D,H,W), src/out
+ * [B,C,D,H,W], out must not alias src) and jacobian_determinant's 3-D case (compute_jacobian.py:42-52;
+ * disp [B,3,D,H,W] -> det float64 [B,D,H,W]).  All sizes >= 2. */
+int cf_warp_trilinear_3d(const float* flow, const float* src, float* out, int B, int C, int D, int H, int W, void* stream);
+int cf_jacobian_det_3d(const float* disp, double* det, int B, int D, int H, int W, void* stream);
+
 /* ---------------------------------------------------------------- correlation
  * CorrVolume(radius, stride)(cur, prev) -- source absent from the reference; call sites
  * SegFlowGaussian.py:256-261, :1376-1377; spec in DESIGN.md ("parity unpinned"):
@@ -179,6 +186,14 @@ int cf_tile_accumulate(const float* pred, const float* gauss, float* agg, float*
                        int ly, int ph, int pw, void* stream);
 /* :741-744: probs = agg/cnt ; seg = argmax_K probs (first maximum).  seg uint8 [X,Y]. */
 int cf_tile_finalize(const float* agg, const float* cnt, float* probs, uint8_t* seg, int K, int X, int Y, void* stream);
+/* 3-D twins: _internal_maybe_mirror_and_pred_3D (neural_network.py:506-571; logits/acc [B,K,D,H,W], the three flags undo
+ * the mirroring of axes 2,3,4) and the tile aggregation of _internal_predict_3D_3Dconv_tiled (:381-398; pred [K,px,py,pz],
+ * gauss [px,py,pz] nullable, agg/cnt [K,X,Y,Z]).  cf_tile_finalize serves 3-D volumes as (K, X, Y*Z). */
+int cf_tta_accumulate_3d(const float* logits, float* acc, int B, int K, int D, int H, int W, int flip_d, int flip_h, int flip_w,
+                         float weight, void* stream);
+int cf_flip3d(const float* src, float* dst, int N, int D, int H, int W, int flip_d, int flip_h, int flip_w, void* stream);
+int cf_tile_accumulate_3d(const float* pred, const float* gauss, float* agg, float* cnt, int K, int X, int Y, int Z, int lx, int ly,
+                          int lz, int px, int py, int pz, void* stream);
 /* argmax over K of [B,K,HW] -> uint8 [B,HW] */
 int cf_argmax_channels(const float* x, uint8_t* out, int B, int K, int HW, void* stream);
 

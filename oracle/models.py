@@ -717,6 +717,85 @@ class GenericUNet2D(nn.Module):
         return self.seg_outputs[-1](x)
 
 
+
+# ----------------------------------------------------------------------------- Generic_UNet (3D)
+class ConvDropoutNormNonlin3D(nn.Module):
+    """generic_UNet.py:26-69 with conv_op = nn.Conv3d, InstanceNorm3d(affine), LeakyReLU(0.01); kernel 3 -> pad 1, 1 -> 0."""
+
+    def __init__(self, cin, cout, kernel=(3, 3, 3), stride=(1, 1, 1)):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, tuple(kernel), stride=tuple(stride), padding=tuple(1 if k == 3 else 0 for k in kernel), bias=True)
+        self.instnorm = nn.InstanceNorm3d(cout, eps=1e-5, affine=True)
+
+    def forward(self, x):
+        return F.leaky_relu(self.instnorm(self.conv(x)), 0.01)
+
+
+class StackedConvLayers3D(nn.Module):
+    """generic_UNet.py:79-144."""
+
+    def __init__(self, cin, cout, num_convs, kernel, first_stride=None):
+        super().__init__()
+        self.input_channels, self.output_channels = cin, cout
+        self.blocks = nn.Sequential(
+            *([ConvDropoutNormNonlin3D(cin, cout, kernel, first_stride if first_stride is not None else (1, 1, 1))] +
+              [ConvDropoutNormNonlin3D(cout, cout, kernel) for _ in range(num_convs - 1)]))
+
+    def forward(self, x):
+        return self.blocks(x)
+
+
+class GenericUNet3D(nn.Module):
+    """generic_UNet.py:167-408 with conv_op = nn.Conv3d (the network behind _internal_predict_3D_3Dconv_tiled):
+    per-stage pool_op_kernel_sizes / conv_kernel_sizes as in the plans (anisotropic (1,2,2) / (1,3,3) stages allowed),
+    convolutional pooling and upsampling, MAX_NUM_FILTERS_3D = 320.  Returns the full-resolution logits."""
+
+    MAX_NUM_FILTERS_3D = 320
+
+    def __init__(self, input_channels, base_num_features, num_classes, num_pool, num_conv_per_stage=2,
+                 pool_op_kernel_sizes=None, conv_kernel_sizes=None):
+        super().__init__()
+        self.num_classes = num_classes
+        pool = [tuple(p) for p in (pool_op_kernel_sizes or [(2, 2, 2)] * num_pool)]
+        kern = [tuple(k) for k in (conv_kernel_sizes or [(3, 3, 3)] * (num_pool + 1))]
+        self.pool_op_kernel_sizes, self.conv_kernel_sizes = pool, kern
+        ctx, loc, tu, seg = [], [], [], []
+        out_f, in_f = base_num_features, input_channels
+        for d in range(num_pool):
+            ctx.append(StackedConvLayers3D(in_f, out_f, num_conv_per_stage, kern[d], pool[d - 1] if d != 0 else None))
+            in_f = out_f
+            out_f = min(int(np.round(out_f * 2)), self.MAX_NUM_FILTERS_3D)
+        final = out_f
+        ctx.append(nn.Sequential(StackedConvLayers3D(in_f, out_f, num_conv_per_stage - 1, kern[num_pool], pool[-1]),
+                                 StackedConvLayers3D(out_f, final, 1, kern[num_pool])))
+        for u in range(num_pool):
+            from_down = final
+            from_skip = ctx[-(2 + u)].output_channels
+            final = from_skip
+            tu.append(nn.ConvTranspose3d(from_down, from_skip, pool[-(u + 1)], pool[-(u + 1)], bias=False))
+            loc.append(nn.Sequential(StackedConvLayers3D(from_skip * 2, from_skip, num_conv_per_stage - 1, kern[-(u + 1)]),
+                                     StackedConvLayers3D(from_skip, final, 1, kern[-(u + 1)])))
+        for ds in range(len(loc)):
+            seg.append(nn.Conv3d(loc[ds][-1].output_channels, num_classes, 1, 1, 0, 1, 1, False))
+        self.conv_blocks_localization = nn.ModuleList(loc)
+        self.conv_blocks_context = nn.ModuleList(ctx)
+        self.td = nn.ModuleList([])
+        self.tu = nn.ModuleList(tu)
+        self.seg_outputs = nn.ModuleList(seg)
+
+    def forward(self, x):
+        skips = []
+        for d in range(len(self.conv_blocks_context) - 1):
+            x = self.conv_blocks_context[d](x)
+            skips.append(x)
+        x = self.conv_blocks_context[-1](x)
+        for u in range(len(self.tu)):
+            x = self.tu[u](x)
+            x = torch.cat((x, skips[-(u + 1)]), dim=1)
+            x = self.conv_blocks_localization[u](x)
+        return self.seg_outputs[-1](x)
+
+
 # ----------------------------------------------------------------------------- sliding-window inference
 def mirror_and_predict_2d(net, x, mirror_axes=(0, 1), do_mirroring=True, mult=None):
     """SegmentationNetwork._internal_maybe_mirror_and_pred_2D, neural_network.py:573-621.
@@ -773,6 +852,65 @@ def predict_3d_2dconv_tiled(net, x, patch_size, **kw):
         segs.append(s[None])
         probs.append(p[None])
     return np.vstack(segs), np.vstack(probs).transpose((1, 0, 2, 3))
+
+
+
+def mirror_and_predict_3d(net, x, mirror_axes=(0, 1, 2), do_mirroring=True, mult=None):
+    """SegmentationNetwork._internal_maybe_mirror_and_pred_3D, neural_network.py:506-571.
+    net: callable [B,C,X,Y,Z] -> logits [B,K,X,Y,Z]; the result tensor is [1,K,...] and broadcasts like the reference's."""
+    result = torch.zeros([1, net.num_classes] + list(x.shape[2:]), dtype=torch.float)
+    n = 2 ** len(mirror_axes) if do_mirroring else 1
+    sm = lambda t: torch.softmax(t, 1)
+    for m in range(8 if do_mirroring else 1):
+        if m == 0:
+            result = result + 1 / n * sm(net(x))
+        if m == 1 and (2 in mirror_axes):
+            result = result + 1 / n * torch.flip(sm(net(torch.flip(x, (4,)))), (4,))
+        if m == 2 and (1 in mirror_axes):
+            result = result + 1 / n * torch.flip(sm(net(torch.flip(x, (3,)))), (3,))
+        if m == 3 and (2 in mirror_axes) and (1 in mirror_axes):
+            result = result + 1 / n * torch.flip(sm(net(torch.flip(x, (4, 3)))), (4, 3))
+        if m == 4 and (0 in mirror_axes):
+            result = result + 1 / n * torch.flip(sm(net(torch.flip(x, (2,)))), (2,))
+        if m == 5 and (0 in mirror_axes) and (2 in mirror_axes):
+            result = result + 1 / n * torch.flip(sm(net(torch.flip(x, (4, 2)))), (4, 2))
+        if m == 6 and (0 in mirror_axes) and (1 in mirror_axes):
+            result = result + 1 / n * torch.flip(sm(net(torch.flip(x, (3, 2)))), (3, 2))
+        if m == 7 and (0 in mirror_axes) and (1 in mirror_axes) and (2 in mirror_axes):
+            result = result + 1 / n * torch.flip(sm(net(torch.flip(x, (4, 3, 2)))), (4, 3, 2))
+    if mult is not None:
+        result[:, :] *= mult
+    return result
+
+
+def predict_3d_tiled(net, x, patch_size, step_size=0.5, do_mirroring=True, mirror_axes=(0, 1, 2), use_gaussian=True,
+                     pad_border_mode="constant", pad_kwargs=None):
+    """SegmentationNetwork._internal_predict_3D_3Dconv_tiled, neural_network.py:292-430 (all_in_gpu=False branch).
+    x: numpy [C,X,Y,Z] -> (seg [X,Y,Z], softmax [K,X,Y,Z])."""
+    assert len(x.shape) == 4, "x must be (c, x, y, z)"
+    data, slicer = ops.pad_nd_image(x, patch_size, pad_border_mode, pad_kwargs, True, None)
+    steps = ops.compute_steps_for_sliding_window(patch_size, data.shape[1:], step_size)
+    num_tiles = len(steps[0]) * len(steps[1]) * len(steps[2])
+    if use_gaussian and num_tiles > 1:
+        g = ops.get_gaussian(patch_size, sigma_scale=1.0 / 8)
+        gauss_t = torch.from_numpy(g)
+        add = g
+    else:
+        gauss_t = None
+        add = np.ones(patch_size, dtype=np.float32)
+    agg = np.zeros([net.num_classes] + list(data.shape[1:]), dtype=np.float32)
+    cnt = np.zeros([net.num_classes] + list(data.shape[1:]), dtype=np.float32)
+    px, py, pz = patch_size
+    for lx in steps[0]:
+        for ly in steps[1]:
+            for lz in steps[2]:
+                tile = torch.from_numpy(np.ascontiguousarray(data[None, :, lx:lx + px, ly:ly + py, lz:lz + pz]))
+                pred = mirror_and_predict_3d(net, tile, mirror_axes, do_mirroring, gauss_t)[0].numpy()
+                agg[:, lx:lx + px, ly:ly + py, lz:lz + pz] += pred
+                cnt[:, lx:lx + px, ly:ly + py, lz:lz + pz] += add
+    sl = tuple([slice(0, agg.shape[i]) for i in range(len(agg.shape) - (len(slicer) - 1))] + slicer[1:])
+    probs = agg[sl] / cnt[sl]
+    return probs.argmax(0), probs
 
 
 # ----------------------------------------------------------------------------- Processor crop arithmetic

@@ -131,6 +131,15 @@ def main():
             vref = vi(flow.clone())
             pin("VecInt " + tag, vref, OO.vecint(flow.clone(), 7), 0.0)
             save("warp_" + tag, flow=flow, src=src, warped=ref, vecint=vref)
+        # 3-D branch (integration.py:75-77)
+        B, C, D, H, W = 2, 2, 6, 10, 8
+        flow3 = 1.5 * randn(B, 3, D, H, W, seed=30)
+        src3 = randn(B, C, D, H, W, seed=31)
+        ref3 = SpatialTransformer((D, H, W))(flow3.clone(), src3)
+        pin("SpatialTransformer 3-D", ref3, OO.warp_bilinear(flow3.clone(), src3), 0.0)
+        vref3 = VecInt((D, H, W), 7)(flow3.clone())
+        pin("VecInt 3-D", vref3, OO.vecint(flow3.clone(), 7), 0.0)
+        save("warp_3d", flow=flow3, src=src3, warped=ref3, vecint=vref3)
         # 256x256: smooth field, store a corner + checksum
         H = W = 256
         flow = torch.nn.functional.avg_pool2d(randn(1, 2, H + 32, W + 32, seed=12), 33, stride=1) * 120.0
@@ -303,6 +312,41 @@ def main():
         tta = SegmentationNetwork._internal_maybe_mirror_and_pred_2D(ref, x, (0, 1), True, None)
         pin("TTA mirror", tta, OM.mirror_and_predict_2d(ora, x, (0, 1), True, None), 1e-6)
         save("tta", x=x, probs=tta)
+
+        # ------------------------------------------------------------------ a3/a4/a5, 3-D: Generic_UNet(conv_op=Conv3d), 8-flip TTA, tiled
+        pool3, kern3 = [[1, 2, 2], [2, 2, 2]], [[1, 3, 3], [3, 3, 3], [3, 3, 3]]
+        ref = Generic_UNet(1, 4, 3, 2, 2, 2, torch.nn.Conv3d, torch.nn.InstanceNorm3d, {"eps": 1e-5, "affine": True},
+                           torch.nn.Dropout3d, {"p": 0, "inplace": True}, torch.nn.LeakyReLU,
+                           {"negative_slope": 1e-2, "inplace": True}, True, False, lambda x: x, InitWeights_He(1e-2),
+                           pool3, kern3, False, True, True)
+        ref.eval()
+        ref.do_ds = False
+        fill_module_(ref, 20)
+        ora = OM.GenericUNet3D(1, 4, 3, 2, pool_op_kernel_sizes=pool3, conv_kernel_sizes=kern3)
+        ora.load_state_dict(ref.state_dict(), strict=True)
+        x3 = randn(1, 1, 8, 16, 16, seed=50)
+        o3 = ref(x3)
+        pin("Generic_UNet 3-D", o3, ora(x3), 1e-5)
+        ref.inference_apply_nonlin = lambda t: torch.softmax(t, 1)
+        g3 = torch.from_numpy(OO.get_gaussian((8, 16, 16)))
+        tta3 = SegmentationNetwork._internal_maybe_mirror_and_pred_3D(ref, x3, (0, 1, 2), True, g3)
+        pin("TTA mirror 3-D", tta3, OM.mirror_and_predict_3d(ora, x3, (0, 1, 2), True, g3), 1e-6)
+        tta3b = SegmentationNetwork._internal_maybe_mirror_and_pred_3D(ref, x3, (1, 2), True, None)
+        pin("TTA mirror 3-D axes (1,2)", tta3b, OM.mirror_and_predict_3d(ora, x3, (1, 2), True, None), 1e-6)
+        vol = randn(1, 11, 24, 20, seed=51).numpy()   # smaller than the patch along x, larger along y and z
+        # batchgenerators (un-vendored) supplies pad_nd_image; the reference module gets the oracle's restatement (parity
+        # unpinned for the padding arithmetic itself) -- everything around it is the reference's own code
+        import nnunet.network_architecture.neural_network as _nn_mod
+        _nn_mod.pad_nd_image = OO.pad_nd_image
+        ref.get_device = lambda: "cpu"
+        ref._gaussian_3d = None
+        ref._patch_size_for_gaussian_3d = None
+        seg_r, prob_r = SegmentationNetwork._internal_predict_3D_3Dconv_tiled(ref, vol, 0.5, True, (0, 1, 2), (8, 16, 16), None, True,
+                                                                              "constant", {"constant_values": 0}, False, False)
+        seg_o, prob_o = OM.predict_3d_tiled(ora, vol, (8, 16, 16), 0.5, True, (0, 1, 2), True, "constant", {"constant_values": 0})
+        pin("_internal_predict_3D_3Dconv_tiled softmax", prob_r, prob_o, 1e-6)
+        assert (seg_r == seg_o).all()
+        save("generic_unet_3d", x=x3, logits=o3, tta=tta3, tta12=tta3b, vol=vol, tiled_prob=prob_r, tiled_seg=seg_r.astype(np.uint8))
 
         # ------------------------------------------------------------------ a14 SegFlowGaussian (both dispatches)
         T = 4

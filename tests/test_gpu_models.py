@@ -114,6 +114,34 @@ def test_generic_unet_and_tta(dev, golden):
     check(mirror_and_predict_2d(m, T(g["x"]).to(dev), (0, 1), True, None), g["probs"], 2e-5)
 
 
+def test_generic_unet_3d_tta_and_tiled(dev, golden):
+    """3-D rows of SURVEY 8a (a3 `_internal_predict_3D_3Dconv_tiled`, a4 8-flip TTA, a5 with conv_op = Conv3d) against
+    the REFERENCE's outputs: anisotropic first stage ((1,3,3) kernels, (1,2,2) pooling), then isotropic."""
+    from cineflow.models import Generic_UNet3D
+    from cineflow.inference import mirror_and_predict_3d, predict_3D_3Dconv_tiled, _gaussian_on
+    from oracle import ops as OO
+    g = golden("generic_unet_3d")
+    pool3, kern3 = [[1, 2, 2], [2, 2, 2]], [[1, 3, 3], [3, 3, 3], [3, 3, 3]]
+    m = load(Generic_UNet3D(1, 4, 3, 2, pool_op_kernel_sizes=pool3, conv_kernel_sizes=kern3), 20, dev)
+    x = T(g["x"]).to(dev)
+    check(m(x), g["logits"], 1e-4, "Generic_UNet 3-D logits")
+    check(mirror_and_predict_3d(m, x, (0, 1, 2), True, _gaussian_on(dev, (8, 16, 16))), g["tta"], 2e-5, "8-flip TTA x Gaussian")
+    check(mirror_and_predict_3d(m, x, (1, 2), True, None), g["tta12"], 2e-5, "TTA axes (1,2)")
+    seg, prob = predict_3D_3Dconv_tiled(m, g["vol"], (8, 16, 16), 0.5, True, (0, 1, 2), True, "constant", {"constant_values": 0})
+    check(torch.from_numpy(prob), g["tiled_prob"], 2e-5, "tiled softmax")
+    agree = float((seg == g["tiled_seg"]).mean())
+    assert agree >= 0.999, agree
+    for k in (1, 2):
+        assert abs(OO.dice(seg, g["tiled_seg"], k) - 1.0) <= 1e-3
+    # exact fp32 kernels give the same answer
+    from cineflow import ops
+    ops.set_conv_mode("f32")
+    try:
+        check(m(x), g["logits"], 1e-4, "fp32 mode")
+    finally:
+        ops.set_conv_mode("f16s")
+
+
 @pytest.mark.parametrize("tag,ma,ff", [("ma", True, 64), ("cv", False, 48)])
 def test_segflow_reference_golden(dev, golden, tag, ma, ff):
     """The reduced-width SegFlowGaussian against the REFERENCE's output (T=4): the north-star EPE bar."""

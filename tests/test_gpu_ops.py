@@ -31,7 +31,7 @@ def randn(*shape, seed):
 
 
 # ------------------------------------------------------------------------------------------------ warp family
-@pytest.mark.parametrize("tag", ["32", "40x24"])
+@pytest.mark.parametrize("tag", ["32", "40x24", "3d"])
 def test_warp_golden(dev, golden, tag):
     from cineflow import ops
     g = golden("warp_" + tag)
@@ -103,6 +103,25 @@ def test_warp_labels(dev, golden):
         assert abs(OO.dice(out.numpy(), ref.numpy(), k) - 1.0) <= 1e-3
 
 
+def test_warp_3d_properties(dev):
+    """3-D branch at a realistic volume size: zero flow is the identity, a pure integer shift moves the volume and zero-fills,
+    and the oracle agrees on a random field."""
+    from cineflow import ops
+    from oracle import ops as OO
+    B, C, D, H, W = 1, 2, 12, 96, 80
+    src = randn(B, C, D, H, W, seed=40)
+    out = ops.warp_bilinear(torch.zeros(B, 3, D, H, W, device=dev), src.to(dev)).cpu()
+    check(out, src, 1e-4, "identity (the reference's normalise round trip is not exact either: 3.8e-5 at 256, SURVEY 8a a16)")
+    flow = torch.zeros(B, 3, D, H, W)
+    flow[:, 0], flow[:, 1], flow[:, 2] = 2.0, -3.0, 5.0
+    out = ops.warp_bilinear(flow.to(dev), src.to(dev)).cpu()
+    ref = torch.zeros_like(src)
+    ref[:, :, :D - 2, 3:, :W - 5] = src[:, :, 2:, :H - 3, 5:]
+    check(out, ref, 2e-4, "integer shift")
+    flow = 2.0 * randn(B, 3, D, H, W, seed=41)
+    check(ops.warp_bilinear(flow.to(dev), src.to(dev)), OO.warp_bilinear(flow.clone(), src), 5e-5, "random field (coordinate rounding scales with the extent: eps*96 px)")
+
+
 def test_memory_input(dev):
     from cineflow import ops
     from oracle import ops as OO
@@ -124,6 +143,14 @@ def test_jacobian(dev, golden):
     big = 4 * randn(2, 2, 256, 256, seed=10)
     ref = np.stack([OO.jacobian_determinant(big[b].permute(1, 2, 0).numpy().astype(np.float64)) for b in range(2)])
     check(ops.jacobian_det(big.to(dev)), ref, 1e-10)
+    # 3-D case (compute_jacobian.py:42-52)
+    disp3 = T(g["disp3"]).float()  # [D,H,W,3]
+    det3 = ops.jacobian_det(disp3.permute(3, 0, 1, 2)[None].contiguous().to(dev))
+    check(det3[0], OO.jacobian_determinant(disp3.numpy().astype(np.float64)), 1e-12)
+    check(ops.jacobian_det(torch.zeros(1, 3, 4, 9, 5, device=dev)), np.ones((1, 4, 9, 5)), 0)
+    big3 = 2 * randn(1, 3, 10, 64, 48, seed=42)
+    ref3 = OO.jacobian_determinant(big3[0].permute(1, 2, 3, 0).numpy().astype(np.float64))
+    check(ops.jacobian_det(big3.to(dev))[0], ref3, 1e-10)
 
 
 # ------------------------------------------------------------------------------------------------ correlation

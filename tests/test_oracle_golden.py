@@ -68,7 +68,7 @@ def test_gaussian(golden):
     assert g256.max() == 1.0 and g256.min() > 0
 
 
-@pytest.mark.parametrize("tag", ["32", "40x24"])
+@pytest.mark.parametrize("tag", ["32", "40x24", "3d"])
 def test_warp_and_vecint(golden, tag):
     g = golden("warp_" + tag)
     close(OO.warp_bilinear(T(g["flow"]).clone(), T(g["src"])), g["warped"], 0)
@@ -178,6 +178,22 @@ def test_generic_unet_and_tta(golden):
         close(m(T(g["x"])), g["logits"], 1e-5)
         g = golden("tta")
         close(OM.mirror_and_predict_2d(m, T(g["x"]), (0, 1), True, None), g["probs"], 1e-6)
+
+
+def test_generic_unet_3d_tta_and_tiled(golden):
+    """3-D rows (a3/a4/a5 with conv_op = Conv3d): the oracle against the reference's own Generic_UNet, 8-flip TTA and
+    _internal_predict_3D_3Dconv_tiled outputs."""
+    g = golden("generic_unet_3d")
+    pool3, kern3 = [[1, 2, 2], [2, 2, 2]], [[1, 3, 3], [3, 3, 3], [3, 3, 3]]
+    with torch.no_grad():
+        m = fill_module_(OM.GenericUNet3D(1, 4, 3, 2, pool_op_kernel_sizes=pool3, conv_kernel_sizes=kern3), 20)
+        close(m(T(g["x"])), g["logits"], 1e-5)
+        g3 = torch.from_numpy(OO.get_gaussian((8, 16, 16)))
+        close(OM.mirror_and_predict_3d(m, T(g["x"]), (0, 1, 2), True, g3), g["tta"], 1e-6)
+        close(OM.mirror_and_predict_3d(m, T(g["x"]), (1, 2), True, None), g["tta12"], 1e-6)
+        seg, prob = OM.predict_3d_tiled(m, g["vol"], (8, 16, 16), 0.5, True, (0, 1, 2), True, "constant", {"constant_values": 0})
+    close(prob, g["tiled_prob"], 1e-6)
+    assert (seg == g["tiled_seg"]).all()
 
 
 @pytest.mark.parametrize("tag,ma,ff", [("ma", True, 64), ("cv", False, 48)])
