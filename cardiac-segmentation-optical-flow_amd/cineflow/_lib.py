@@ -24,6 +24,7 @@ P = ctypes.c_void_p
 I = ctypes.c_int
 L = ctypes.c_long
 F = ctypes.c_float
+DBL = ctypes.c_double
 
 # name -> argtypes, exactly the prototypes of include/cineflow.h (tests/test_abi.py checks both directions)
 SIGNATURES = {
@@ -61,6 +62,10 @@ SIGNATURES = {
     "cf_flip3d": [P, P, I, I, I, I, I, I, I, P],
     "cf_tile_accumulate_3d": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cf_argmax_channels": [P, P, I, I, I, P],
+    "cf_cc_init": [P, P, L, P, I, P],
+    "cf_cc_sweep": [P, I, I, I, P, P],
+    "cf_cc_count": [P, P, L, P],
+    "cf_cc_remove": [P, P, P, L, I, DBL, DBL, P],
     "cf_profile_enable": [I],
     "cf_profile_reset": [],
     "cf_profile_read": [I, P, P, P],

@@ -456,3 +456,50 @@ def argmax_channels(x):
     out = torch.empty((B,) + tuple(x.shape[2:]), dtype=torch.uint8, device=x.device)
     check(lib().cf_argmax_channels(_f32(x), _u8(out), B, K, HW, _stream()), "cf_argmax_channels")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ export post-processing
+def remove_all_but_the_largest_connected_component(image, for_which_classes, volume_per_voxel, minimum_valid_object_size=None):
+    """nnunet/postprocessing/connected_components.py:51-107 on the device.  image: uint8 device tensor [Z,Y,X] or [Y,X]
+    (modified in place); for_which_classes: ints or tuples of ints (joint regions) or None (all foreground labels).
+    Returns (image, largest_removed, kept_size) like the reference."""
+    import ctypes
+    assert image.dtype == torch.uint8 and image.is_cuda and image.is_contiguous()
+    shape = tuple(image.shape)
+    D, H, W = (1,) * (3 - len(shape)) + shape
+    n = image.numel()
+    if for_which_classes is None:
+        for_which_classes = [int(v) for v in torch.unique(image).tolist() if v > 0]
+    assert 0 not in for_which_classes, "cannot remove background"
+    labels = torch.empty(n, dtype=torch.int32, device=image.device)
+    counts = torch.empty(n, dtype=torch.int32, device=image.device)
+    changed = torch.zeros(1, dtype=torch.int32, device=image.device)
+    largest_removed, kept_size = {}, {}
+    for c in for_which_classes:
+        key = tuple(c) if isinstance(c, (list, tuple)) else c
+        vals = list(key) if isinstance(key, tuple) else [key]
+        cls = (ctypes.c_uint8 * len(vals))(*[int(v) for v in vals])
+        check(lib().cf_cc_init(_u8(image), labels.data_ptr(), n, ctypes.cast(cls, ctypes.c_void_p), len(vals), _stream()), "cf_cc_init")
+        while True:
+            changed.zero_()
+            for _ in range(8):
+                check(lib().cf_cc_sweep(labels.data_ptr(), D, H, W, changed.data_ptr(), _stream()), "cf_cc_sweep")
+            if int(changed.item()) == 0:
+                break
+        counts.zero_()
+        check(lib().cf_cc_count(labels.data_ptr(), counts.data_ptr(), n, _stream()), "cf_cc_count")
+        sizes = counts[counts > 0]
+        largest_removed[key] = None
+        kept_size[key] = None
+        if sizes.numel() > 0:
+            max_count = int(sizes.max().item())
+            kept_size[key] = max_count * volume_per_voxel
+            thr = -1.0 if minimum_valid_object_size is None else float(minimum_valid_object_size[key])
+            gone = sizes[sizes != max_count]
+            if thr >= 0:
+                gone = gone[gone.double() * volume_per_voxel < thr]
+            if gone.numel() > 0:
+                largest_removed[key] = int(gone.max().item()) * volume_per_voxel
+            check(lib().cf_cc_remove(_u8(image), labels.data_ptr(), counts.data_ptr(), n, max_count, float(volume_per_voxel), thr, _stream()),
+                  "cf_cc_remove")
+    return image, largest_removed, kept_size

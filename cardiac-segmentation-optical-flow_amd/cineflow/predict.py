@@ -190,6 +190,31 @@ def save_segmentation_nifti_from_softmax(segmentation_softmax, out_fname, proper
         write_nifti(registered_path, np.asarray(registered[0]).astype(np.uint8), *geo)
 
 
+# ------------------------------------------------------------------------------------------------ post-processing
+def load_postprocessing(json_file):
+    """connected_components.py:109-120."""
+    import ast
+    with open(json_file) as f:
+        a = json.load(f)
+    mv = ast.literal_eval(a["min_valid_object_sizes"]) if "min_valid_object_sizes" in a else None
+    return a["for_which_classes"], mv
+
+
+def load_remove_save(input_file, output_file, for_which_classes, minimum_valid_object_size=None):
+    """connected_components.py:31-48: keep the largest connected component of each class (device kernels, cineflow.ops)."""
+    img, props = read_nifti(input_file)
+    volume_per_voxel = float(np.prod(props["itk_spacing"], dtype=np.float64))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = torch.from_numpy(np.ascontiguousarray(img.astype(np.uint8))).to(dev)
+    fw = [tuple(c) if isinstance(c, list) else c for c in for_which_classes] if for_which_classes is not None else None
+    mv = None
+    if minimum_valid_object_size is not None:
+        mv = {(tuple(k) if isinstance(k, list) else k): v for k, v in minimum_valid_object_size.items()}
+    t, largest_removed, kept_size = ops.remove_all_but_the_largest_connected_component(t, fw, volume_per_voxel, mv)
+    write_nifti(output_file, t.cpu().numpy(), props["itk_spacing"], props["itk_origin"], props["itk_direction"])
+    return largest_removed, kept_size
+
+
 # ------------------------------------------------------------------------------------------------ predict API
 def subfiles(folder, suffix=None, join_=True, sort=True):
     res = [f for f in os.listdir(folder) if os.path.isfile(join(folder, f)) and (suffix is None or f.endswith(suffix))]
@@ -232,43 +257,136 @@ def _subfolder_path(path, sub):
     return join(os.path.dirname(path), sub, os.path.basename(path))
 
 
-def predict_cases(model, list_of_lists, output_filenames, folds, save_npz, num_threads_preprocessing, num_threads_nifti_save,
-                  segs_from_prev_stage=None, do_tta=True, mixed_precision=True, overwrite_existing=False, all_in_gpu=False,
-                  step_size=0.5, checkpoint_name="model_final_checkpoint", segmentation_export_kwargs=None,
-                  disable_postprocessing=False, ed_index=0):
-    """predict.py:228-354 + predict_flow :1008-1130 for ONE patient: `list_of_lists[t]` = the modality files of frame t.
-    All frames form the cine sequence; frame `ed_index` is rotated to the front for the ED-anchored recurrence."""
-    assert len(list_of_lists) == len(output_filenames)
-    trainer, params = load_model_and_checkpoint_files(model, folds, mixed_precision=mixed_precision, checkpoint_name=checkpoint_name)
-    trainer.load_checkpoint_ram(params[0], False)
-    for o in output_filenames:
-        for sub in ("Segmentation", "Flow", "Registered"):
-            os.makedirs(join(os.path.dirname(o), sub), exist_ok=True)
-    pre = [trainer.preprocess_patient(l) for l in list_of_lists]                # predict.py:302
-    d = [p[0] for p in pre]
-    property_list = [p[2] for p in pre]
-    T = len(d)
-    order = list(range(ed_index, T)) + list(range(0, ed_index))                 # ED first (trainer SegFlowGaussian.py:1005-1013)
-    unlabeled = np.stack([d[i] for i in order]) + 1e-8                           # predict.py:1025
+def get_ed_es_indices(csv_filepath):
+    """predict.py:1196-1198: first row of the patient's csv, columns `ed_index`, `es_index`."""
+    with open(csv_filepath) as f:
+        rows = list(csv.DictReader(f))
+    return int(float(rows[0]["ed_index"])), int(float(rows[0]["es_index"]))
+
+
+def put_ed_first(current_list_of_lists, current_output_files, csv_filepath):
+    """predict.py:1165-1193: rotate the frame list so that the end-diastolic frame comes first."""
+    ed_index, _es = get_ed_es_indices(csv_filepath)
+    order = list(range(ed_index, len(current_list_of_lists))) + list(range(0, ed_index))
+    return [list(current_list_of_lists[i]) for i in order], [current_output_files[i] for i in order]
+
+
+def predict_flow(d, trainer, output_filenames, property_list, do_tta, mixed_precision, params, interpolation_order, force_separate_z,
+                 interpolation_order_z, all_in_gpu, step_size, save_npz, disable_postprocessing, model, pool):
+    """predict.py:1008-1162 for one patient: `d[t]` = preprocessed frame t (ED first), all frames form the cine sequence.
+    Writes <patient>/{Segmentation,Flow,Registered}/<case>; returns the three path lists."""
+    unlabeled = np.stack(d) + 1e-8                                               # predict.py:1025
     print("predicting", output_filenames)
     seg, softmax, flow, registered, _raw = trainer.predict_preprocessed_data_return_seg_and_softmax_flow(
         unlabeled=unlabeled, target=None, target_mask=None, processor=trainer.processor, do_mirroring=do_tta,
         mirror_axes=trainer.data_aug_params["mirror_axes"], use_sliding_window=True, step_size=step_size, use_gaussian=True,
         all_in_gpu=all_in_gpu, mixed_precision=mixed_precision, verbose=False)
-    pool = ThreadPool(max(1, num_threads_nifti_save))
-    jobs = []
-    for j, t in enumerate(order):
-        out = output_filenames[t]
-        seg_path, flow_path, reg_path = (_subfolder_path(out, s) for s in ("Segmentation", "Flow", "Registered"))
+    assert len(softmax) == len(flow) == len(registered)
+    seg_paths, flow_paths, reg_paths, jobs = [], [], [], []
+    for t in range(len(softmax)):
+        seg_path, flow_path, reg_path = (_subfolder_path(output_filenames[t], s_) for s_ in ("Segmentation", "Flow", "Registered"))
+        seg_paths.append(seg_path)
+        flow_paths.append(flow_path[:-7] + ".npz")
+        reg_paths.append(reg_path)
         npz = seg_path[:-7] + ".npz" if save_npz else None
         jobs.append(pool.apply_async(save_segmentation_nifti_from_softmax,
-                                     (softmax[j], seg_path, property_list[t], 1, None, None, None, npz, None, None, 0, False, flow[j],
-                                      flow_path[:-7] + ".npz", registered[j], reg_path)))
+                                     (softmax[t], seg_path, property_list[t], interpolation_order, None, None, None, npz, None,
+                                      force_separate_z, interpolation_order_z, False, flow[t], flow_paths[-1], registered[t], reg_path)))
+    print("inference done. Now waiting for the segmentation export to finish...")
     [j.get() for j in jobs]
-    pool.close()
-    pool.join()
+    if not disable_postprocessing:
+        pp_file = join(model, "postprocessing.json")
+        if os.path.isfile(pp_file):                                              # predict.py:1139-1156
+            print("postprocessing...")
+            shutil.copy(pp_file, os.path.abspath(os.path.dirname(output_filenames[0])))
+            for_which_classes, min_valid_obj_size = load_postprocessing(pp_file)
+            for pth in seg_paths + reg_paths:
+                load_remove_save(pth, pth, for_which_classes, min_valid_obj_size)
+        else:
+            print("WARNING! Cannot run postprocessing because the postprocessing file is missing (%s)" % model)
+    return seg_paths, flow_paths, reg_paths
+
+
+def predict_non_flow(d, trainer, output_filenames, property_list, do_tta, mixed_precision, params, interpolation_order, force_separate_z,
+                     interpolation_order_z, all_in_gpu, step_size, save_npz, disable_postprocessing, model, pool):
+    """predict.py:926-1005: segmentation only, frame by frame, sliding window + TTA, fold ensembling."""
+    jobs = []
+    for t, input_img in enumerate(d):
+        print("predicting", output_filenames[t])
+        trainer.load_checkpoint_ram(params[0], False)
+        softmax = trainer.predict_preprocessed_data_return_seg_and_softmax(
+            input_img, do_mirroring=do_tta, mirror_axes=trainer.data_aug_params["mirror_axes"], use_sliding_window=True,
+            step_size=step_size, use_gaussian=True, all_in_gpu=all_in_gpu, mixed_precision=mixed_precision)[1]
+        for p_ in params[1:]:
+            trainer.load_checkpoint_ram(p_, False)
+            softmax += trainer.predict_preprocessed_data_return_seg_and_softmax(
+                input_img, do_mirroring=do_tta, mirror_axes=trainer.data_aug_params["mirror_axes"], use_sliding_window=True,
+                step_size=step_size, use_gaussian=True, all_in_gpu=all_in_gpu, mixed_precision=mixed_precision)[1]
+        if len(params) > 1:
+            softmax /= len(params)
+        npz = output_filenames[t][:-7] + ".npz" if save_npz else None
+        jobs.append(pool.apply_async(save_segmentation_nifti_from_softmax,
+                                     (softmax, output_filenames[t], property_list[t], interpolation_order, None, None, None, npz, None,
+                                      force_separate_z, interpolation_order_z)))
+    return jobs
+
+
+def predict_cases(model, list_of_lists, output_filenames, folds, save_npz, num_threads_preprocessing, num_threads_nifti_save,
+                  segs_from_prev_stage=None, do_tta=True, mixed_precision=True, overwrite_existing=False, all_in_gpu=False,
+                  step_size=0.5, checkpoint_name="model_final_checkpoint", segmentation_export_kwargs=None,
+                  disable_postprocessing=False, ed_index=0):
+    """predict.py:228-354 for ONE patient: `list_of_lists[t]` = the modality files of frame t.  All frames form the cine
+    sequence; frame `ed_index` is rotated to the front for the ED-anchored recurrence (put_ed_first, :1165-1193)."""
+    assert len(list_of_lists) == len(output_filenames)
+    if segs_from_prev_stage is not None:
+        assert len(segs_from_prev_stage) == len(output_filenames)
+    trainer, params = load_model_and_checkpoint_files(model, folds, mixed_precision=mixed_precision, checkpoint_name=checkpoint_name)
+    if segmentation_export_kwargs is None:                                       # predict.py:286-296
+        exp = trainer.plans.get("segmentation_export_params") or {}
+        force_separate_z = exp.get("force_separate_z")
+        interpolation_order = exp.get("interpolation_order", 1)
+        interpolation_order_z = exp.get("interpolation_order_z", 0)
+    else:
+        force_separate_z = segmentation_export_kwargs["force_separate_z"]
+        interpolation_order = segmentation_export_kwargs["interpolation_order"]
+        interpolation_order_z = segmentation_export_kwargs["interpolation_order_z"]
+    trainer.load_checkpoint_ram(params[0], False)
+    for o in output_filenames:
+        for sub in ("Segmentation", "Flow", "Registered"):
+            os.makedirs(join(os.path.dirname(o), sub), exist_ok=True)
+    T = len(list_of_lists)
+    order = list(range(ed_index, T)) + list(range(0, ed_index))                 # ED first
+    pre = [trainer.preprocess_patient(list_of_lists[i]) for i in order]         # predict.py:302
+    pool = ThreadPool(max(1, num_threads_nifti_save))
+    try:
+        predict_flow([p_[0] for p_ in pre], trainer, [output_filenames[i] for i in order], [p_[2] for p_ in pre], do_tta, mixed_precision,
+                     params, interpolation_order, force_separate_z, interpolation_order_z, all_in_gpu, step_size, save_npz,
+                     disable_postprocessing, model, pool)
+    finally:
+        pool.close()
+        pool.join()
     return [(_subfolder_path(o, "Segmentation"), _subfolder_path(o, "Flow")[:-7] + ".npz", _subfolder_path(o, "Registered"))
             for o in output_filenames]
+
+
+def predict_cases_fast(model, list_of_lists, output_filenames, folds, num_threads_preprocessing, num_threads_nifti_save,
+                       segs_from_prev_stage=None, do_tta=True, mixed_precision=True, overwrite_existing=False, all_in_gpu=False,
+                       step_size=0.5, checkpoint_name="model_final_checkpoint", segmentation_export_kwargs=None,
+                       disable_postprocessing=False):
+    """predict.py:356-501 ("fast": no resampled-softmax npz).  Everything already stays on the GPU here, so this is
+    predict_cases with save_npz=False."""
+    return predict_cases(model, list_of_lists, output_filenames, folds, False, num_threads_preprocessing, num_threads_nifti_save,
+                         segs_from_prev_stage, do_tta, mixed_precision, overwrite_existing, all_in_gpu, step_size, checkpoint_name,
+                         segmentation_export_kwargs, disable_postprocessing)
+
+
+def predict_cases_fastest(model, list_of_lists, output_filenames, folds, num_threads_preprocessing, num_threads_nifti_save,
+                          segs_from_prev_stage=None, do_tta=True, mixed_precision=True, overwrite_existing=False, all_in_gpu=False,
+                          step_size=0.5, checkpoint_name="model_final_checkpoint", disable_postprocessing=False):
+    """predict.py:504-626 ("fastest": argmax on the device, nearest-neighbour export)."""
+    return predict_cases(model, list_of_lists, output_filenames, folds, False, num_threads_preprocessing, num_threads_nifti_save,
+                         segs_from_prev_stage, do_tta, mixed_precision, overwrite_existing, all_in_gpu, step_size, checkpoint_name,
+                         {"force_separate_z": None, "interpolation_order": 0, "interpolation_order_z": 0}, disable_postprocessing)
 
 
 def predict_from_folder(model, input_folder, output_folder, folds, save_npz, num_threads_preprocessing, num_threads_nifti_save,
@@ -299,10 +417,7 @@ def predict_from_folder(model, input_folder, output_folder, folds, save_npz, num
         ed_index = 0
         csv_path = join(current_input_folder, patient + ".csv")                  # predict.py:700, :1196-1198
         if os.path.isfile(csv_path):
-            with open(csv_path) as f:
-                rows = list(csv.DictReader(f))
-            if rows and "ed_index" in rows[0]:
-                ed_index = int(float(rows[0]["ed_index"]))
+            ed_index = get_ed_es_indices(csv_path)[0]
         results[patient] = predict_cases(model, list_of_lists, output_files, folds, save_npz, num_threads_preprocessing,
                                          num_threads_nifti_save, None, tta, mixed_precision=mixed_precision,
                                          overwrite_existing=overwrite_existing, all_in_gpu=bool(overwrite_all_in_gpu), step_size=step_size,

@@ -197,6 +197,19 @@ int cf_tile_accumulate_3d(const float* pred, const float* gauss, float* agg, flo
 /* argmax over K of [B,K,HW] -> uint8 [B,HW] */
 int cf_argmax_channels(const float* x, uint8_t* out, int B, int K, int HW, void* stream);
 
+/* ---------------------------------------------------------------- export post-processing
+ * remove_all_but_the_largest_connected_component, nnunet/postprocessing/connected_components.py:51-107, on the device.
+ * scipy.ndimage.label's default structure (face neighbours).  labels int32 [n]: 0 = outside the region, else 1 + the
+ * smallest voxel index of the component once cf_cc_sweep has converged (*changed stays 0 after a sweep; the caller
+ * zeroes it before each sweep and reads it back).  `classes`: HOST array of the 1..8 label values forming the region. */
+int cf_cc_init(const uint8_t* image, int* labels, long n, const uint8_t* classes, int nclasses, void* stream);
+int cf_cc_sweep(int* labels, int D, int H, int W, int* changed, void* stream);
+/* counts int32 [n], zero-initialised by the caller: counts[l-1] += 1 for every voxel with label l */
+int cf_cc_count(const int* labels, int* counts, long n, void* stream);
+/* image[i] = 0 where the voxel's component size differs from max_count and (min_valid < 0 or size*volume_per_voxel < min_valid) */
+int cf_cc_remove(uint8_t* image, const int* labels, const int* counts, long n, int max_count, double volume_per_voxel,
+                 double min_valid, void* stream);
+
 /* ---------------------------------------------------------------- measurement hooks (bench.py only; no reference analogue)
  * cf_profile_enable(n): pre-create n event pairs and time every conv / CorrVolume launch with a (start, stop) pair that
  * brackets exactly that kernel on its own stream (hipExtLaunchKernelGGL); 0 disables.  Kernel ids:

@@ -264,3 +264,38 @@ def mean_epe(a, b):
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
     return float(torch.sqrt(((a - b) ** 2).sum(dim=-3)).mean())
+
+
+# --------------------------------------------------------------------------- export post-processing
+def remove_all_but_the_largest_connected_component(image, for_which_classes, volume_per_voxel, minimum_valid_object_size=None):
+    """nnunet/postprocessing/connected_components.py:51-107 (scipy.ndimage.label, default face connectivity)."""
+    from scipy.ndimage import label
+    if for_which_classes is None:
+        for_which_classes = np.unique(image)
+        for_which_classes = for_which_classes[for_which_classes > 0]
+    assert 0 not in for_which_classes, "cannot remove background"
+    largest_removed, kept_size = {}, {}
+    for c in for_which_classes:
+        if isinstance(c, (list, tuple)):
+            c = tuple(c)
+            mask = np.zeros_like(image, dtype=bool)
+            for cl in c:
+                mask[image == cl] = True
+        else:
+            mask = image == c
+        lmap, num_objects = label(mask.astype(int))
+        object_sizes = {i: (lmap == i).sum() * volume_per_voxel for i in range(1, num_objects + 1)}
+        largest_removed[c] = None
+        kept_size[c] = None
+        if num_objects > 0:
+            maximum_size = max(object_sizes.values())
+            kept_size[c] = maximum_size
+            for i in range(1, num_objects + 1):
+                if object_sizes[i] != maximum_size:
+                    remove = True
+                    if minimum_valid_object_size is not None:
+                        remove = object_sizes[i] < minimum_valid_object_size[c]
+                    if remove:
+                        image[(lmap == i) & mask] = 0
+                        largest_removed[c] = object_sizes[i] if largest_removed[c] is None else max(largest_removed[c], object_sizes[i])
+    return image, largest_removed, kept_size

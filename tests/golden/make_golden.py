@@ -348,6 +348,30 @@ def main():
         assert (seg_r == seg_o).all()
         save("generic_unet_3d", x=x3, logits=o3, tta=tta3, tta12=tta3b, vol=vol, tiled_prob=prob_r, tiled_seg=seg_r.astype(np.uint8))
 
+        # ------------------------------------------------------------------ f1 largest-connected-component filter of the export
+        try:
+            from nnunet.postprocessing.connected_components import remove_all_but_the_largest_connected_component as ref_cc
+        except Exception as e:   # evaluator / SimpleITK import chain: record why and keep the restatement unpinned
+            ref_cc = None
+            print("  connected_components not importable here (%s): largest-component filter stays parity-unpinned" % type(e).__name__)
+        rng = np.random.RandomState(60)
+        blobs = (torch.nn.functional.avg_pool3d(torch.from_numpy(rng.rand(1, 1, 10, 70, 70).astype(np.float32)), 7, 1, 0)[0, 0].numpy())
+        lab = np.zeros(blobs.shape, np.uint8)
+        lab[blobs > 0.52] = 1
+        lab[blobs > 0.545] = 2
+        lab[blobs < 0.455] = 3
+        cases_cc = [([1, 2, 3], None), ([(1, 2), 3], None), ([1, 2], {1: 40.0, 2: 1e9}), (None, None)]
+        outs = []
+        for fw, mv in cases_cc:
+            o_img, o_lr, o_ks = OO.remove_all_but_the_largest_connected_component(lab.copy(), fw, 1.5, mv)
+            if ref_cc is not None:
+                r_img, r_lr, r_ks = ref_cc(lab.copy(), fw, 1.5, mv)
+                pin("remove_all_but_the_largest_connected_component %s" % (fw,), r_img.astype(np.float32), o_img.astype(np.float32), 0.0)
+                assert r_lr == o_lr and r_ks == o_ks, (r_lr, o_lr, r_ks, o_ks)
+                o_img = r_img
+            outs.append(o_img)
+        save("connected_components", labels=lab, out0=outs[0], out1=outs[1], out2=outs[2], out3=outs[3])
+
         # ------------------------------------------------------------------ a14 SegFlowGaussian (both dispatches)
         T = 4
         frames = randn(T, 1, 1, S, S, seed=37)

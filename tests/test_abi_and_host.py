@@ -29,6 +29,8 @@ def _header_prototypes():
                     kinds.append("L")
                 elif re.match(r"(const\s+)?float\b", a):
                     kinds.append("F")
+                elif re.match(r"(const\s+)?double\b", a):
+                    kinds.append("D")
                 elif re.match(r"(const\s+)?int\b", a):
                     kinds.append("I")
                 else:
@@ -51,7 +53,7 @@ def test_ctypes_signatures_match_header():
     from cineflow import _lib
     protos = _header_prototypes()
     protos.pop("cf_version")
-    kind = {ctypes.c_void_p: "P", ctypes.c_int: "I", ctypes.c_long: "L", ctypes.c_float: "F"}
+    kind = {ctypes.c_void_p: "P", ctypes.c_int: "I", ctypes.c_long: "L", ctypes.c_float: "F", ctypes.c_double: "D"}
     assert set(protos) == set(_lib.SIGNATURES), set(protos) ^ set(_lib.SIGNATURES)
     for name, argtypes in _lib.SIGNATURES.items():
         assert [kind[a] for a in argtypes] == protos[name], name

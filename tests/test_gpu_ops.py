@@ -527,3 +527,28 @@ def test_tta_and_tiles(dev):
     assert torch.equal(seg.cpu().long(), (ra / rc.clamp(min=1e-3)).argmax(0))
     am = ops.argmax_channels(logits.to(dev))
     assert torch.equal(am.cpu().long(), logits.argmax(1))
+
+
+# ------------------------------------------------------------------------------------------------ export post-processing
+def test_connected_component_filter(dev, golden):
+    """Largest-connected-component filter (connected_components.py:51-107) on the device vs the reference's outputs."""
+    from cineflow import ops
+    from oracle import ops as OO
+    g = golden("connected_components")
+    cases = [([1, 2, 3], None), ([(1, 2), 3], None), ([1, 2], {1: 40.0, 2: 1e9}), (None, None)]
+    for i, (fw, mv) in enumerate(cases):
+        img = torch.from_numpy(g["labels"].copy()).to(dev)
+        out, largest_removed, kept = ops.remove_all_but_the_largest_connected_component(img, fw, 1.5, mv)
+        assert (out.cpu().numpy() == g["out%d" % i]).all(), "case %d" % i
+        _, lr_o, ks_o = OO.remove_all_but_the_largest_connected_component(g["labels"].copy(), fw, 1.5, mv)
+        assert kept == ks_o and largest_removed == lr_o, (kept, ks_o, largest_removed, lr_o)
+    # 2-D, a long snake (many sweeps) next to a small island, and an empty class
+    img = np.zeros((64, 96), np.uint8)
+    for r in range(0, 64, 4):
+        img[r, 2:94] = 1
+        img[r:r + 4, 93 if (r // 4) % 2 == 0 else 2] = 1
+    img[60:63, 40:44] = 0
+    img[62, 50:53] = 1
+    ref = OO.remove_all_but_the_largest_connected_component(img.copy(), [1, 2], 1.0, None)[0]
+    out = ops.remove_all_but_the_largest_connected_component(torch.from_numpy(img.copy()).to(dev), [1, 2], 1.0, None)[0]
+    assert (out.cpu().numpy() == ref).all()

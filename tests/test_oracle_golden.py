@@ -180,6 +180,14 @@ def test_generic_unet_and_tta(golden):
         close(OM.mirror_and_predict_2d(m, T(g["x"]), (0, 1), True, None), g["probs"], 1e-6)
 
 
+def test_connected_component_filter(golden):
+    g = golden("connected_components")
+    cases = [([1, 2, 3], None), ([(1, 2), 3], None), ([1, 2], {1: 40.0, 2: 1e9}), (None, None)]
+    for i, (fw, mv) in enumerate(cases):
+        out, _, kept = OO.remove_all_but_the_largest_connected_component(g["labels"].copy(), fw, 1.5, mv)
+        assert (out == g["out%d" % i]).all()
+
+
 def test_generic_unet_3d_tta_and_tiled(golden):
     """3-D rows (a3/a4/a5 with conv_op = Conv3d): the oracle against the reference's own Generic_UNet, 8-flip TTA and
     _internal_predict_3D_3Dconv_tiled outputs."""

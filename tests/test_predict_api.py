@@ -47,6 +47,35 @@ def test_api_signatures_match_reference():
                                          "all_in_gpu", "step_size", "checkpoint_name", "segmentation_export_kwargs", "disable_postprocessing"]
 
 
+def test_helper_signatures_match_reference():
+    """predict_flow / predict_non_flow (predict.py:926-941, :1008-1023), the fast variants (:356, :504) and the ED helpers."""
+    from cineflow import predict as P
+    sixteen = ["d", "trainer", "output_filenames", "property_list", "do_tta", "mixed_precision", "params", "interpolation_order",
+               "force_separate_z", "interpolation_order_z", "all_in_gpu", "step_size", "save_npz", "disable_postprocessing", "model", "pool"]
+    assert list(inspect.signature(P.predict_flow).parameters) == sixteen
+    assert list(inspect.signature(P.predict_non_flow).parameters) == sixteen
+    assert list(inspect.signature(P.predict_cases_fast).parameters) == [
+        "model", "list_of_lists", "output_filenames", "folds", "num_threads_preprocessing", "num_threads_nifti_save", "segs_from_prev_stage",
+        "do_tta", "mixed_precision", "overwrite_existing", "all_in_gpu", "step_size", "checkpoint_name", "segmentation_export_kwargs",
+        "disable_postprocessing"]
+    assert list(inspect.signature(P.predict_cases_fastest).parameters) == [
+        "model", "list_of_lists", "output_filenames", "folds", "num_threads_preprocessing", "num_threads_nifti_save", "segs_from_prev_stage",
+        "do_tta", "mixed_precision", "overwrite_existing", "all_in_gpu", "step_size", "checkpoint_name", "disable_postprocessing"]
+    assert list(inspect.signature(P.put_ed_first).parameters) == ["current_list_of_lists", "current_output_files", "csv_filepath"]
+    assert list(inspect.signature(P.load_remove_save).parameters) == ["input_file", "output_file", "for_which_classes",
+                                                                     "minimum_valid_object_size"]
+
+
+def test_put_ed_first(tmp_path):
+    from cineflow import predict as P
+    csvp = str(tmp_path / "p.csv")
+    with open(csvp, "w") as f:
+        f.write("ed_index,es_index\n2,4\n")
+    assert P.get_ed_es_indices(csvp) == (2, 4)
+    lol, outs = P.put_ed_first([["a0"], ["a1"], ["a2"], ["a3"]], ["o0", "o1", "o2", "o3"], csvp)
+    assert lol == [["a2"], ["a3"], ["a0"], ["a1"]] and outs == ["o2", "o3", "o0", "o1"]
+
+
 def test_case_discovery_and_errors(tmp_path):
     from cineflow.predict import check_input_folder_and_return_caseIDs, predict_from_folder
     from cineflow.nifti import write_nifti
@@ -142,3 +171,19 @@ def test_predict_from_folder_end_to_end(dev, tmp_path):
     # part_id / num_parts sharding = the reference's [part_id::num_parts]
     res1 = P.predict_from_folder(model, str(inp), str(tmp_path / "out1"), [0], False, 1, 1, None, 1, 2, False)
     assert sorted(res1) == ["patient002"]
+    # postprocessing.json in the model folder (predict.py:1139-1156): only the largest component of each class survives
+    import json
+    from oracle import ops as OO
+    with open(os.path.join(model, "postprocessing.json"), "w") as f:
+        json.dump({"for_which_classes": [1, 2, 3]}, f)
+    P.predict_from_folder(model, str(inp), str(tmp_path / "out2"), [0], False, 1, 1, None, 1, 2, False)
+    for t in range(T):
+        case = "patient002_frame%02d" % t
+        raw, _ = read_nifti(str(tmp_path / "out1" / "patient002" / "Segmentation" / (case + ".nii.gz")))
+        pp, _ = read_nifti(str(tmp_path / "out2" / "patient002" / "Segmentation" / (case + ".nii.gz")))
+        ref = OO.remove_all_but_the_largest_connected_component(raw.copy(), [1, 2, 3], 1.5 * 1.5 * 8.0, None)[0]
+        assert np.array_equal(pp, ref)
+    # the reference's helper entry points exist with its argument lists
+    for name in ("predict_flow", "predict_non_flow", "predict_cases_fast", "predict_cases_fastest", "put_ed_first", "get_ed_es_indices",
+                 "load_remove_save", "load_postprocessing"):
+        assert callable(getattr(P, name))
