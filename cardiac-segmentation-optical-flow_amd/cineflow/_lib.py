@@ -62,6 +62,7 @@ SIGNATURES = {
     "cf_flip3d": [P, P, I, I, I, I, I, I, I, P],
     "cf_tile_accumulate_3d": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cf_argmax_channels": [P, P, I, I, I, P],
+    "cf_resize3d": [P, P, I, I, I, I, I, I, I, I, I, I, P],
     "cf_cc_init": [P, P, L, P, I, P],
     "cf_cc_sweep": [P, I, I, I, P, P],
     "cf_cc_count": [P, P, L, P],

@@ -4,6 +4,7 @@ PyTorch is used for device memory (torch.empty on the caching allocator) and the
 number is produced by a hand-written HIP kernel in libcineflow_hip.so.  Inputs must be CUDA(=HIP) tensors; nothing
 here runs on the CPU and nothing falls back to torch operators.
 """
+import numpy as np
 import torch
 
 from ._lib import lib, check
@@ -459,6 +460,42 @@ def argmax_channels(x):
 
 
 # ------------------------------------------------------------------------------------------------ export post-processing
+def resize3d(src, new_shape, linear=(1, 1, 1)):
+    """src [N,X,Y,Z] float32 -> [N,*new_shape]; per axis linear (order 1) or nearest (order 0); skimage 'edge' semantics."""
+    N, X, Y, Z = src.shape
+    X2, Y2, Z2 = (int(v) for v in new_shape)
+    dst = torch.empty((N, X2, Y2, Z2), dtype=torch.float32, device=src.device)
+    check(lib().cf_resize3d(_f32(src), _f32(dst), N, X, Y, Z, X2, Y2, Z2, int(linear[0]), int(linear[1]), int(linear[2]), _stream()),
+          "cf_resize3d")
+    return dst
+
+
+def resample_data_or_seg(data, new_shape, is_seg, axis=None, order=3, do_separate_z=False, order_z=0):
+    """nnunet/preprocessing/preprocessing.py:111-200 on the device for the orders the export uses (0 and 1).  data: numpy or
+    device tensor (c, x, y, z); returns the same kind.  Segmentations of order 0 are nearest-neighbour in every axis; data is
+    linear in-plane and `order_z` along the anisotropic axis when do_separate_z."""
+    was_numpy = not torch.is_tensor(data)
+    t = torch.from_numpy(np.ascontiguousarray(data)) if was_numpy else data
+    dtype_in = t.dtype
+    assert t.dim() == 4 and len(new_shape) == 3, "data must be (c, x, y, z)"
+    if tuple(t.shape[1:]) == tuple(int(v) for v in new_shape):
+        return data
+    if order not in (0, 1) or order_z not in (0, 1):
+        raise NotImplementedError("export resampling is built for interpolation orders 0 and 1 (got %s / %s)" % (order, order_z))
+    if is_seg and order != 0:
+        raise NotImplementedError("segmentation resampling is built for order 0")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lin = [int(order)] * 3
+    if do_separate_z:
+        assert len(axis) == 1, "only one anisotropic axis supported"
+        lin[int(axis[0])] = int(order_z)
+    out = resize3d(t.to(dev, dtype=torch.float32).contiguous(), new_shape, lin)
+    if is_seg:
+        out = out.round()
+    out = out.to(dtype_in)
+    return out.cpu().numpy() if was_numpy else out
+
+
 def remove_all_but_the_largest_connected_component(image, for_which_classes, volume_per_voxel, minimum_valid_object_size=None):
     """nnunet/postprocessing/connected_components.py:51-107 on the device.  image: uint8 device tensor [Z,Y,X] or [Y,X]
     (modified in place); for_which_classes: ints or tuples of ints (joint regions) or None (all foreground labels).

@@ -169,21 +169,94 @@ def load_model_and_checkpoint_files(folder, folds=None, mixed_precision=None, ch
 
 
 # ------------------------------------------------------------------------------------------------ export
+RESAMPLING_SEPARATE_Z_ANISO_THRESHOLD = 3   # nnunet/configuration.py
+
+
+def get_do_separate_z(spacing, anisotropy_threshold=RESAMPLING_SEPARATE_Z_ANISO_THRESHOLD):
+    """preprocessing.py:30-32."""
+    return (np.max(spacing) / np.min(spacing)) > anisotropy_threshold
+
+
+def get_lowres_axis(new_spacing):
+    """preprocessing.py:35-37."""
+    return np.where(max(new_spacing) / np.array(new_spacing) == 1)[0]
+
+
 def save_segmentation_nifti_from_softmax(segmentation_softmax, out_fname, properties_dict, order=1, region_class_order=None,
                                          seg_postprogess_fn=None, seg_postprocess_args=None, resampled_npz_fname=None,
                                          non_postprocessed_fname=None, force_separate_z=None, interpolation_order_z=0, verbose=True,
                                          flow=None, flow_path=None, registered=None, registered_path=None):
-    """segmentation_export.py:29-223 for the no-resampling case: argmax -> uint8 NIfTI with the case's geometry;
-    flow [2,Z,Y,X] -> npz `flow` [Y,X,Z,2] float32 + `spacing`; registered [1,Z,Y,X] -> uint8 NIfTI."""
+    """segmentation_export.py:29-223: resample softmax / flow / registered labels back to the size before resampling (device
+    kernels, cineflow.ops.resample_data_or_seg), rescale the flow to the new pixel grid, argmax, place into the crop bounding
+    box, write uint8 NIfTI with the case's geometry; flow [2,Z,Y,X] -> npz `flow` [Y,X,Z,2] float32 + `spacing`."""
     if isinstance(segmentation_softmax, str):
+        assert os.path.isfile(segmentation_softmax), "If isinstance(segmentation_softmax, str) then isfile(segmentation_softmax) must be True"
+        del_file = segmentation_softmax
         segmentation_softmax = np.load(segmentation_softmax)
-    shape = tuple(properties_dict.get("size_after_cropping"))
-    assert tuple(segmentation_softmax.shape[1:]) == shape, "resampling on export is not built yet (SURVEY section 8f row 1)"
+        os.remove(del_file)
+    current_shape = segmentation_softmax.shape
+    shape_after_crop = tuple(properties_dict.get("size_after_cropping"))
+    shape_before_crop = properties_dict.get("original_size_of_raw_data")
+    if any(i != j for i, j in zip(current_shape[1:], shape_after_crop)):
+        if force_separate_z is None:                                             # segmentation_export.py:88-98
+            if get_do_separate_z(properties_dict.get("original_spacing")):
+                do_separate_z, lowres_axis = True, get_lowres_axis(properties_dict.get("original_spacing"))
+            elif get_do_separate_z(properties_dict.get("spacing_after_resampling")):
+                do_separate_z, lowres_axis = True, get_lowres_axis(properties_dict.get("spacing_after_resampling"))
+            else:
+                do_separate_z, lowres_axis = False, None
+        else:
+            do_separate_z = force_separate_z
+            lowres_axis = get_lowres_axis(properties_dict.get("original_spacing")) if do_separate_z else None
+        if lowres_axis is not None and len(lowres_axis) != 1:
+            do_separate_z = False
+        if verbose:
+            print("separate z:", do_separate_z, "lowres axis", lowres_axis)
+        seg_old_spacing = ops.resample_data_or_seg(segmentation_softmax, shape_after_crop, is_seg=False, axis=lowres_axis, order=order,
+                                                   do_separate_z=do_separate_z, order_z=interpolation_order_z)
+        if flow is not None:
+            rescale_y = shape_after_crop[1] / flow.shape[2]
+            rescale_x = shape_after_crop[2] / flow.shape[3]
+            flow = ops.resample_data_or_seg(np.asarray(flow, np.float32), shape_after_crop, is_seg=False, axis=lowres_axis, order=order,
+                                            do_separate_z=do_separate_z, order_z=interpolation_order_z)
+            flow[0] = flow[0] * rescale_y                                        # segmentation_export.py:123-124
+            flow[1] = flow[1] * rescale_x
+        if registered is not None:
+            registered = ops.resample_data_or_seg(np.asarray(registered), shape_after_crop, is_seg=True, axis=lowres_axis, order=0,
+                                                  do_separate_z=do_separate_z, order_z=0)
+    else:
+        if verbose:
+            print("no resampling necessary")
+        seg_old_spacing = segmentation_softmax
     if resampled_npz_fname is not None:
-        np.savez_compressed(resampled_npz_fname, softmax=segmentation_softmax.astype(np.float16))
-    seg = segmentation_softmax.argmax(0).astype(np.uint8)
+        np.savez_compressed(resampled_npz_fname, softmax=seg_old_spacing.astype(np.float16))
+    if region_class_order is None:
+        seg = seg_old_spacing.argmax(0)
+    else:
+        seg = np.zeros(seg_old_spacing.shape[1:])
+        for i, c in enumerate(region_class_order):
+            seg[seg_old_spacing[i] > 0.5] = c
+    bbox = properties_dict.get("crop_bbox")
+    if bbox is not None:                                                         # segmentation_export.py:153-177
+        bbox = [list(b) for b in bbox]
+        for c in range(3):
+            bbox[c][1] = int(np.min((bbox[c][0] + seg.shape[c], shape_before_crop[c])))
+        sl = tuple(slice(b[0], b[1]) for b in bbox)
+        full = np.zeros(shape_before_crop, dtype=np.uint8)
+        full[sl] = seg
+        seg = full
+        if flow is not None:
+            f_full = np.zeros([2] + list(shape_before_crop), dtype=np.float32)
+            f_full[(slice(None),) + sl] = flow
+            flow = f_full
+        if registered is not None:
+            r_full = np.zeros(shape_before_crop, dtype=np.uint8)
+            r_full[sl] = registered[0]
+            registered = r_full[None]
+    if seg_postprogess_fn is not None:
+        seg = seg_postprogess_fn(np.copy(seg), *seg_postprocess_args)
     geo = (properties_dict["itk_spacing"], properties_dict["itk_origin"], properties_dict["itk_direction"])
-    write_nifti(out_fname, seg, *geo)
+    write_nifti(out_fname, seg.astype(np.uint8), *geo)
     if flow is not None:
         np.savez(flow_path, flow=np.asarray(flow, np.float32).transpose(2, 3, 1, 0), spacing=properties_dict["itk_spacing"])
     if registered is not None:

@@ -63,6 +63,49 @@ __global__ void __launch_bounds__(256) cc_remove_kernel(uint8_t* __restrict__ im
     }
 }
 
+// Export resampling (resample_data_or_seg, nnunet/preprocessing/preprocessing.py:111-200): skimage.transform.resize(mode='edge',
+// anti_aliasing=False) / map_coordinates(mode='nearest') sample at src = scale * (dst + 0.5) - 0.5 with edge clamping; per axis
+// either linear (order 1) or nearest (order 0, floor(src + 0.5)).  Coordinates in double like the reference.
+struct ResizeAxis {
+    int i0, i1;
+    float w1;
+};
+__device__ __forceinline__ ResizeAxis resize_axis(int o, int n_src, int n_dst, int linear) {
+    const double s = ((double)n_src / (double)n_dst) * ((double)o + 0.5) - 0.5;
+    ResizeAxis a;
+    if (linear) {
+        const double f = floor(s);
+        int i = (int)f;
+        a.w1 = (float)(s - f);
+        a.i0 = min(max(i, 0), n_src - 1);
+        a.i1 = min(max(i + 1, 0), n_src - 1);
+    } else {
+        a.i0 = a.i1 = min(max((int)floor(s + 0.5), 0), n_src - 1);
+        a.w1 = 0.f;
+    }
+    return a;
+}
+
+__global__ void __launch_bounds__(256) resize3d_kernel(const float* __restrict__ src, float* __restrict__ dst, int X, int Y, int Z, int X2,
+                                                       int Y2, int Z2, int lx, int ly, int lz, long total) {
+    const long V2 = (long)X2 * Y2 * Z2, V = (long)X * Y * Z;
+    GRID_STRIDE(i, total) {
+        const long n = i / V2, p = i - n * V2;
+        const int z = (int)(p % Z2);
+        const long r = p / Z2;
+        const int y = (int)(r % Y2), x = (int)(r / Y2);
+        const ResizeAxis ax = resize_axis(x, X, X2, lx), ay = resize_axis(y, Y, Y2, ly), az = resize_axis(z, Z, Z2, lz);
+        const float* s = src + n * V;
+        auto at = [&](int a, int b, int c) { return s[((long)a * Y + b) * Z + c]; };
+        auto lerp = [](float u, float v, float w) { return u + (v - u) * w; };
+        const float c00 = lerp(at(ax.i0, ay.i0, az.i0), at(ax.i0, ay.i0, az.i1), az.w1);
+        const float c01 = lerp(at(ax.i0, ay.i1, az.i0), at(ax.i0, ay.i1, az.i1), az.w1);
+        const float c10 = lerp(at(ax.i1, ay.i0, az.i0), at(ax.i1, ay.i0, az.i1), az.w1);
+        const float c11 = lerp(at(ax.i1, ay.i1, az.i0), at(ax.i1, ay.i1, az.i1), az.w1);
+        dst[i] = lerp(lerp(c00, c01, ay.w1), lerp(c10, c11, ay.w1), ax.w1);
+    }
+}
+
 }  // namespace cf
 
 using namespace cf;
@@ -98,4 +141,12 @@ extern "C" int cf_cc_remove(uint8_t* image, const int* labels, const int* counts
                             double min_valid, void* stream) {
     CF_REQUIRE(image && labels && counts && n > 0, "bad arguments");
     LAUNCH_FLAT(cc_remove_kernel, n, image, labels, counts, n, max_count, volume_per_voxel, min_valid);
+}
+
+extern "C" int cf_resize3d(const float* src, float* dst, int N, int X, int Y, int Z, int X2, int Y2, int Z2, int linear_x, int linear_y,
+                           int linear_z, void* stream) {
+    CF_REQUIRE(src && dst && src != dst, "null or aliased pointer");
+    CF_REQUIRE(N > 0 && X > 0 && Y > 0 && Z > 0 && X2 > 0 && Y2 > 0 && Z2 > 0, "bad shape");
+    const long total = (long)N * X2 * Y2 * Z2;
+    LAUNCH_FLAT(resize3d_kernel, total, src, dst, X, Y, Z, X2, Y2, Z2, linear_x, linear_y, linear_z, total);
 }

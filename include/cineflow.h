@@ -210,6 +210,12 @@ int cf_cc_count(const int* labels, int* counts, long n, void* stream);
 int cf_cc_remove(uint8_t* image, const int* labels, const int* counts, long n, int max_count, double volume_per_voxel,
                  double min_valid, void* stream);
 
+/* resample_data_or_seg, nnunet/preprocessing/preprocessing.py:111-200 (export path, orders 0 and 1): src [N,X,Y,Z] ->
+ * dst [N,X2,Y2,Z2], sampling at src = (n/n2)*(dst+0.5)-0.5 with edge clamping (skimage resize mode='edge',
+ * map_coordinates mode='nearest'); per axis linear (1) or nearest (0). */
+int cf_resize3d(const float* src, float* dst, int N, int X, int Y, int Z, int X2, int Y2, int Z2, int linear_x, int linear_y,
+                int linear_z, void* stream);
+
 /* ---------------------------------------------------------------- measurement hooks (bench.py only; no reference analogue)
  * cf_profile_enable(n): pre-create n event pairs and time every conv / CorrVolume launch with a (start, stop) pair that
  * brackets exactly that kernel on its own stream (hipExtLaunchKernelGGL); 0 disables.  Kernel ids:

@@ -299,3 +299,33 @@ def remove_all_but_the_largest_connected_component(image, for_which_classes, vol
                         image[(lmap == i) & mask] = 0
                         largest_removed[c] = object_sizes[i] if largest_removed[c] is None else max(largest_removed[c], object_sizes[i])
     return image, largest_removed, kept_size
+
+
+def resample_data_or_seg(data, new_shape, is_seg, axis=None, order=3, do_separate_z=False, order_z=0):
+    """nnunet/preprocessing/preprocessing.py:111-200 restated without skimage / batchgenerators (both absent: PARITY UNPINNED).
+    skimage.transform.resize(order, mode='edge', anti_aliasing=False) and batchgenerators' resize_segmentation(order 0) both
+    sample at src = scale*(dst+0.5)-0.5 with edge clamping = scipy map_coordinates(order, mode='nearest') on that map."""
+    from scipy.ndimage import map_coordinates
+    assert len(data.shape) == 4 and len(new_shape) == 3
+    shape = np.array(data[0].shape)
+    new_shape = np.array(new_shape)
+    if not np.any(shape != new_shape):
+        return data
+    dtype_data = data.dtype
+    orders = [order] * 3
+    if do_separate_z:
+        assert len(axis) == 1
+        orders[int(axis[0])] = order_z
+    out = []
+    for c in range(data.shape[0]):
+        vol = data[c].astype(float)
+        # separable: resample one axis at a time (in-plane first, like the reference's per-slice resize followed by the z pass)
+        for ax in sorted(range(3), key=lambda a: (do_separate_z and a == int(axis[0]) if axis is not None and len(axis) else False)):
+            n_src, n_dst = vol.shape[ax], int(new_shape[ax])
+            if n_src == n_dst:
+                continue
+            coords = (float(n_src) / n_dst) * (np.arange(n_dst) + 0.5) - 0.5
+            grids = np.meshgrid(*[coords if a == ax else np.arange(vol.shape[a], dtype=float) for a in range(3)], indexing="ij")
+            vol = map_coordinates(vol, np.array(grids), order=orders[ax], mode="nearest")
+        out.append(vol[None].astype(dtype_data))
+    return np.vstack(out)

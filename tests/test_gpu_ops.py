@@ -552,3 +552,27 @@ def test_connected_component_filter(dev, golden):
     ref = OO.remove_all_but_the_largest_connected_component(img.copy(), [1, 2], 1.0, None)[0]
     out = ops.remove_all_but_the_largest_connected_component(torch.from_numpy(img.copy()).to(dev), [1, 2], 1.0, None)[0]
     assert (out.cpu().numpy() == ref).all()
+
+
+@pytest.mark.parametrize("shape,new,order,sep,axis,oz", [((5, 20, 24), (5, 31, 40), 1, True, [0], 0), ((5, 20, 24), (8, 31, 17), 1, True, [0], 0),
+                                                          ((6, 20, 24), (9, 15, 40), 1, False, None, 0), ((4, 33, 21), (4, 50, 50), 0, False, None, 0),
+                                                          ((5, 20, 24), (7, 30, 30), 1, True, [0], 1)])
+def test_export_resampling(dev, shape, new, order, sep, axis, oz):
+    """resample_data_or_seg (preprocessing.py:111-200) for the orders the export uses, against the numpy/scipy restatement
+    (skimage and batchgenerators are absent: parity unpinned)."""
+    from cineflow import ops
+    from oracle import ops as OO
+    rng = np.random.RandomState(3)
+    data = rng.rand(3, *shape).astype(np.float32)
+    ref = OO.resample_data_or_seg(data, new, False, axis, order, sep, oz)
+    out = ops.resample_data_or_seg(data, new, False, axis, order, sep, oz)
+    assert out.shape == ref.shape == (3,) + tuple(new) and out.dtype == np.float32
+    check(torch.from_numpy(out), ref, 2e-6, "data order %d" % order)
+    seg = rng.randint(0, 4, (1,) + tuple(shape)).astype(np.uint8)
+    ref = OO.resample_data_or_seg(seg, new, True, axis, 0, sep, 0)
+    out = ops.resample_data_or_seg(seg, new, True, axis, 0, sep, 0)
+    assert out.dtype == np.uint8 and np.array_equal(out, ref)
+    # identity and constant fields
+    assert ops.resample_data_or_seg(data, shape, False, axis, order, sep, oz) is data
+    const = np.full((1,) + tuple(shape), 2.5, np.float32)
+    check(torch.from_numpy(ops.resample_data_or_seg(const, new, False, axis, order, sep, oz)), np.full((1,) + tuple(new), 2.5), 1e-6)

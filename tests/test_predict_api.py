@@ -122,6 +122,48 @@ def test_exporter_layout(tmp_path):
 
 
 @pytest.mark.gpu
+def test_exporter_resampling_and_crop_bbox(dev, tmp_path):
+    """segmentation_export.py:82-177: softmax / flow / registered labels resampled back to the size before resampling (flow
+    rescaled to the new grid), then placed into the crop bounding box of the raw image."""
+    from cineflow.predict import save_segmentation_nifti_from_softmax
+    from cineflow.nifti import read_nifti
+    from oracle import ops as OO
+    rng = np.random.RandomState(2)
+    Z, Y, X = 4, 20, 16                   # network resolution
+    Zo, Yo, Xo = 4, 31, 24                # size after cropping, before resampling
+    soft = rng.rand(4, Z, Y, X).astype(np.float32)
+    flow = rng.randn(2, Z, Y, X).astype(np.float32)
+    reg = rng.randint(0, 4, (1, Z, Y, X)).astype(np.uint8)
+    props = {"size_after_cropping": np.array([Zo, Yo, Xo]), "original_size_of_raw_data": np.array([Zo, 40, 30]),
+             "crop_bbox": [[0, Zo], [5, 5 + Yo], [3, 3 + Xo]], "original_spacing": np.array([8.0, 1.0, 1.0]),
+             "spacing_after_resampling": np.array([8.0, 1.5, 1.5]), "itk_spacing": (1.0, 1.0, 8.0), "itk_origin": (0.0, 0.0, 0.0),
+             "itk_direction": (1, 0, 0, 0, 1, 0, 0, 0, 1)}
+    for sub in ("Segmentation", "Flow", "Registered"):
+        (tmp_path / sub).mkdir()
+    seg_p, flow_p, reg_p = str(tmp_path / "Segmentation" / "c.nii.gz"), str(tmp_path / "Flow" / "c.npz"), str(tmp_path / "Registered" / "c.nii.gz")
+    save_segmentation_nifti_from_softmax(soft, seg_p, props, order=1, flow=flow, flow_path=flow_p, registered=reg, registered_path=reg_p,
+                                         verbose=False)
+    # expected: separate z (8 mm vs 1 mm), linear in-plane, nearest along z
+    s_ref = OO.resample_data_or_seg(soft, (Zo, Yo, Xo), False, [0], 1, True, 0)
+    f_ref = OO.resample_data_or_seg(flow, (Zo, Yo, Xo), False, [0], 1, True, 0)
+    f_ref[0] *= Yo / Y
+    f_ref[1] *= Xo / X
+    r_ref = OO.resample_data_or_seg(reg, (Zo, Yo, Xo), True, [0], 0, True, 0)
+    seg, _ = read_nifti(seg_p)
+    assert seg.shape == (Zo, 40, 30)
+    inner = seg[:, 5:5 + Yo, 3:3 + Xo]
+    agree = float((inner == s_ref.argmax(0)).mean())
+    assert agree > 0.995, agree          # argmax ties at 1e-7 differences only
+    assert seg[:, :5].max() == 0 and seg[:, :, :3].max() == 0 and seg[:, 5 + Yo:].max() == 0
+    f = np.load(flow_p)["flow"]
+    assert f.shape == (40, 30, Zo, 2)
+    assert float(np.abs(f[5:5 + Yo, 3:3 + Xo] - f_ref.transpose(2, 3, 1, 0)).max()) < 1e-5
+    assert float(np.abs(f[:5]).max()) == 0.0
+    r, _ = read_nifti(reg_p)
+    assert np.array_equal(r[:, 5:5 + Yo, 3:3 + Xo], r_ref[0])
+
+
+@pytest.mark.gpu
 def test_predict_from_folder_end_to_end(dev, tmp_path):
     from cineflow import predict as P
     from cineflow.models import SegFlowGaussian, Generic_UNet
