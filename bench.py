@@ -212,7 +212,7 @@ def main():
     roofline_corr = None
     if cn:
         ach = cbytes / (cms * 1e-3) / 1e9
-        roofline_corr = {"bound": "hbm", "kernel": "corr_volume_r4_kernel<1|2|4>", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+        roofline_corr = {"bound": "hbm", "kernel": "corr_volume_p7_kernel<1|2|4> (persistent)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": cn,
                          "avg_launch_us": round(cms * 1e3 / cn, 2),
                          "per_level": {"s%d" % s: {"GB/s": round(c[1] / (c[0] * 1e-3) / 1e9, 1), "avg_launch_us": round(c[0] * 1e3 / c[2], 2)}

@@ -219,7 +219,7 @@ int cf_resize3d(const float* src, float* dst, int N, int X, int Y, int Z, int X2
 /* ---------------------------------------------------------------- measurement hooks (bench.py only; no reference analogue)
  * cf_profile_enable(n): pre-create n event pairs and time every conv / CorrVolume launch with a (start, stop) pair that
  * brackets exactly that kernel on its own stream (hipExtLaunchKernelGGL); 0 disables.  Kernel ids:
- * 0,1,2 = conv_igemm MT 1,2,4 (work = flops); 3,4,5 = corr_volume_r4 stride 1,2,4 (work = algorithmic bytes);
+ * 0,1,2 = conv_igemm MT 1,2,4 (work = flops); 3,4,5 = corr_volume_p7 stride 1,2,4 (work = algorithmic bytes);
  * 6 = conv_f16s (work = flops).
  * cf_profile_read sums kernel durations [ms], work and launches since the last cf_profile_reset (it synchronises: call it
  * outside the timed region). */
