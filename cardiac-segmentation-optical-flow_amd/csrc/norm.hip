@@ -134,29 +134,64 @@ __global__ void __launch_bounds__(256) gn_apply_flat_kernel(const float* __restr
     }
 }
 
-// LayerNorm over C of channel-first tokens: one thread per token, lanes along N (coalesced), two passes over C
-// (second pass hits L1/L2).
-__global__ void __launch_bounds__(256) layer_norm_cf_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ out, int B,
-                                                            int C, int N, float eps) {
-    const long total = (long)B * N;
-    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        int b = (int)(t / N);
-        int n = (int)(t - (long)b * N);
-        const float* xb = x + (long)b * C * N + n;
-        float* ob = out + (long)b * C * N + n;
-        double s = 0.0, ss = 0.0;
-        for (int c = 0; c < C; ++c) {
-            double v = (double)xb[(long)c * N];
-            s += v;
-            ss += v * v;
+// LayerNorm over C of channel-first tokens [B, C, N].  Block = 64 consecutive tokens (lanes: coalesced along N) x 8 waves,
+// wave g owning channels g, g+8, ...: fp64 partial sums per thread, one LDS combine, then the affine pass.  Up to 32
+// channels per thread stay in registers between the two passes (C <= 256); larger C re-reads (L2 hits).
+constexpr int LN_G = 8, LN_REG = 32;
+__global__ void __launch_bounds__(64 * LN_G) layer_norm_cf_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ out, int B,
+                                                                 int C, int N, float eps) {
+    __shared__ double red[LN_G][64][2];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long t = (long)blockIdx.x * 64 + lane;      // token index over (b, n); a block never straddles... it may: handled per thread
+    const bool valid = t < (long)B * N;
+    const int b = valid ? (int)(t / N) : 0;
+    const int n = valid ? (int)(t - (long)b * N) : 0;
+    const float* xb = x + (long)b * C * N + n;
+    float* ob = out + (long)b * C * N + n;
+    const bool inreg = C <= LN_G * LN_REG;
+    float v[LN_REG];
+    double s = 0.0, ss = 0.0;
+    if (valid) {
+        if (inreg) {
+#pragma unroll
+            for (int k = 0; k < LN_REG; ++k) {
+                const int c = g + k * LN_G;
+                v[k] = c < C ? xb[(long)c * N] : 0.f;
+                s += (double)v[k];
+                ss += (double)v[k] * (double)v[k];
+            }
+        } else {
+            for (int c = g; c < C; c += LN_G) {
+                const double u = (double)xb[(long)c * N];
+                s += u;
+                ss += u * u;
+            }
         }
-        double mean = s / C;
-        double var = ss / C - mean * mean;
-        if (var < 0.0) var = 0.0;
-        float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        float mf = (float)mean;
-        for (int c = 0; c < C; ++c) ob[(long)c * N] = (xb[(long)c * N] - mf) * rstd * gamma[c] + beta[c];
+    }
+    red[g][lane][0] = s;
+    red[g][lane][1] = ss;
+    __syncthreads();
+    s = ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < LN_G; ++k) {
+        s += red[k][lane][0];
+        ss += red[k][lane][1];
+    }
+    if (!valid) return;
+    const double mean = s / C;
+    double var = ss / C - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mf = (float)mean;
+    if (inreg) {
+#pragma unroll
+        for (int k = 0; k < LN_REG; ++k) {
+            const int c = g + k * LN_G;
+            if (c < C) ob[(long)c * N] = (v[k] - mf) * rstd * gamma[c] + beta[c];
+        }
+    } else {
+        for (int c = g; c < C; c += LN_G) ob[(long)c * N] = (xb[(long)c * N] - mf) * rstd * gamma[c] + beta[c];
     }
 }
 
@@ -237,9 +272,10 @@ extern "C" int cf_layer_norm_cf(const float* x, const float* gamma, const float*
                                 void* stream) {
     CF_REQUIRE(x && gamma && beta && out, "null pointer");
     CF_REQUIRE(B > 0 && C > 0 && N > 0, "bad shape");
-    long total = (long)B * N;
-    hipLaunchKernelGGL(layer_norm_cf_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, as_stream(stream), x, gamma, beta, out, B, C,
-                       N, eps);
+    const long total = (long)B * N;
+    CF_REQUIRE((total + 63) / 64 < (1L << 31), "too many tokens");
+    hipLaunchKernelGGL(layer_norm_cf_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64 * LN_G), 0, as_stream(stream), x, gamma, beta,
+                       out, B, C, N, eps);
     CF_CHECK_LAUNCH();
     return CF_OK;
 }

@@ -407,11 +407,13 @@ def test_zscore_whole_block(dev):
     check(normalize_intensity_(x.clone().to(dev)), OO.normalize_intensity(x), 2e-5)
 
 
-def test_layer_norm_cf(dev):
+@pytest.mark.parametrize("B,C,N", [(3, 32, 64), (2, 256, 1024), (1, 512, 100), (2, 7, 33), (1, 300, 70)])
+def test_layer_norm_cf(dev, B, C, N):
+    """register-resident path (C <= 256), re-read path (C > 256), ragged token counts and channel counts"""
     from cineflow import ops
-    x = randn(3, 32, 64, seed=58) * 2 + 0.5
-    g, b = 1 + 0.1 * randn(32, seed=59), 0.1 * randn(32, seed=60)
-    ref = F.layer_norm(x.permute(0, 2, 1), (32,), g, b, 1e-5).permute(0, 2, 1)
+    x = randn(B, C, N, seed=58) * 2 + 0.5
+    g, b = 1 + 0.1 * randn(C, seed=59), 0.1 * randn(C, seed=60)
+    ref = F.layer_norm(x.permute(0, 2, 1), (C,), g, b, 1e-5).permute(0, 2, 1)
     check(ops.layer_norm_cf(x.to(dev), g.to(dev), b.to(dev)), ref, 2e-5)
 
 
