@@ -43,6 +43,7 @@ struct F16sGeom {
     int ostep;               // patch step between output pixels (stride, or 1 for 1x1 convs)
     int tiles_x, tiles_y, bgroups;
     int nchunk;
+    int NQ;                  // vector staging: 16-byte column quads per patch row (0: scalar staging)
 };
 
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
@@ -56,7 +57,7 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 // chunks of loads in flight, always one LDS buffer ahead.  vmcnt retires in issue order, so in the mixed design every
 // wait for a weight fragment also waited for the staging loads issued before it (ablating those loads made the kernel
 // 19-33 % faster); with separate roles nothing in the MFMA waves ever waits for HBM.
-template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW>
+template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC>
 __global__ void __launch_bounds__(64 * NW + 64 * NLW, NLW ? 5 : (NW == 8 ? 2 : ((NTW <= 2 && MAXT <= 3) ? 4 : 2)))
 conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restrict__ wpk) {
     constexpr int KW = (KHW == 9) ? 3 : 1;
@@ -173,6 +174,70 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
         }
     };
 
+
+    // ---- vector staging (VEC): task = 4 image columns aligned to 16 bytes x 4 channels -> 4 buffer_load_dwordx4 instead of 16
+    // buffer_load_dword for the same 16 elements.  Time stamps in the correlation kernel showed ~150-240 cycles per vector-memory
+    // instruction once the CU's address path back-pressures; the scalar staging issues 64 such instructions per workgroup and
+    // chunk, this path 15.  Aligned quads never straddle the image border when W % 4 == 0, so a quad is either wholly inside
+    // (one range-checked load) or wholly padding (offset parked at 2 GiB -> zeros); columns of a quad that lie outside the
+    // patch are simply not written.  Host checks: stride 1, W % 4 == 0, 16-byte aligned tensors, one task per thread.
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    unsigned v_o1 = OOB, v_o2 = OOB, v_c4 = 0, v_mask = 0;
+    int v_lds = 0;
+    if (VEC) {
+        constexpr int NCG = CK / 4;
+        const int xq0 = ix_org & ~3;
+        const int per_cg = g.NIMG * g.PH * g.NQ;
+        const int cg = tid / per_cg;
+        int r = tid - cg * per_cg;
+        if (cg < NCG) {
+            const int img = r / (g.PH * g.NQ);
+            r -= img * (g.PH * g.NQ);
+            const int py = r / g.NQ, q = r - py * g.NQ;
+            const int iy = iy_org + py, xq = xq0 + 4 * q, b = b0 + img;
+            const int pxp = xq - ix_org;                                  // patch column of the quad's first pixel (may be < 0)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v_mask |= ((unsigned)(pxp + k) < (unsigned)g.PW) ? (1u << k) : 0u;
+            v_lds = ((img * g.PH + py) * g.PW + pxp) * REC + cg * 8;
+            v_c4 = cg * 4;
+            if (b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)xq < (unsigned)p.W) {
+                const unsigned sp = (unsigned)(iy * p.W + xq);
+                v_o1 = ((unsigned)b * p.C1 * HW + sp) * 4u;
+                v_o2 = ((unsigned)b * p.C2 * HW + sp) * 4u;
+            }
+        }
+    }
+    auto issue_loads_v = [&](int chunk, f32x4v (&stg)[4]) {
+        const int c0 = chunk * CK;
+        const bool in1 = c0 < p.C1;
+        const unsigned cb = (unsigned)(in1 ? c0 : c0 - p.C1);
+        const unsigned v0 = (in1 ? v_o1 : v_o2) + (cb + v_c4) * HW4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned off = v0 + (unsigned)j * HW4;
+            stg[j] = in1 ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, 0, 0))
+                         : __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, 0, 0));
+        }
+    };
+    auto write_stage_v = [&](int chunk, const f32x4v (&stg)[4]) {
+        unsigned char* base = lds + (chunk & 1) * buf_bytes + v_lds;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!((v_mask >> k) & 1u)) continue;
+            f16x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 h, l;
+                split_f16(stg[j][k], h, l);
+                hi[j] = h;
+                lo[j] = l;
+            }
+            *reinterpret_cast<f16x4*>(base + k * REC) = hi;
+            *reinterpret_cast<f16x4*>(base + k * REC + CK * 2) = lo;
+        }
+    };
+
     if (NLW > 0 && loader) {
         // ---- loader waves: two register sets keep TWO chunks of loads in flight (loop unrolled by two so the sets are
         // statically indexed); the wait in front of each LDS write is for loads issued a whole chunk period earlier.
@@ -243,11 +308,14 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
         aL[slot] = wc[64];
     };
 
-    float stg0[MAXT][8];
-    if (NLW == 0) issue_loads(0, stg0);
+    float stg0[MAXT][8];   // dead (eliminated) in the VEC instantiations
+    f32x4v stgv[4];
+    if (VEC) issue_loads_v(0, stgv);
+    else if (NLW == 0) issue_loads(0, stg0);
 #pragma unroll
     for (int sidx = 0; sidx < D; ++sidx) load_a(0, sidx, sidx % R);
-    if (NLW == 0) write_stage(0, stg0);
+    if (VEC) write_stage_v(0, stgv);
+    else if (NLW == 0) write_stage(0, stg0);
     __syncthreads();
 
     for (int c = 0; c < g.nchunk; ++c) {
@@ -260,7 +328,10 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
             if (step + D < NSTEP) load_a(c, step + D, (step + D) % R);
             else if (more) load_a(c + 1, step + D - NSTEP, (step + D) % R);
             if (NLW == 0 && step == 0) {
-                if (more) issue_loads(c + 1, stg0);
+                if (more) {
+                    if (VEC) issue_loads_v(c + 1, stgv);
+                    else issue_loads(c + 1, stg0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             const int toff = ((tap / KW) * g.PW + (tap % KW)) * REC;
@@ -276,7 +347,10 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nt], 0, 0, 0);
             }
         }
-        if (NLW == 0 && more) write_stage(c + 1, stg0);
+        if (NLW == 0 && more) {
+            if (VEC) write_stage_v(c + 1, stgv);
+            else write_stage(c + 1, stg0);
+        }
         __syncthreads();
     }
 
@@ -374,12 +448,43 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// CF_F16S_VEC=0 keeps the scalar (one dword per lane and channel) staging everywhere
+static int f16s_vec() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CF_F16S_VEC");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC>
+static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s);
+
+// picks the vector-staging instantiation when the layer qualifies (stride 1, W % 4 == 0, 16-byte aligned inputs, one
+// 4x4 task per staging thread), else the scalar one
 template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW = 0, int NW = 4>
 static int launch_f16s(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s) {
+    g.NQ = 0;
+    // (1x1 layers measured 6-17 % slower with it -- their scalar loads are already whole rows -- so 3x3 only)
+    if (NLW == 0 && KHW == 9 && f16s_vec() && p.stride == 1 && (p.W & 3) == 0 && (g.TW & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(p.x1) | reinterpret_cast<uintptr_t>(p.x2)) & 15) == 0) {
+        const int a = (-p.pad_w) & 3;                       // ix_org mod 4 (tile origins are multiples of 4)
+        const int nq = ((a + g.PW - 1) >> 2) + 1;
+        if ((CK / 4) * g.NIMG * g.PH * nq <= 64 * NW) {
+            g.NQ = nq;
+            return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 1>(p, g, wpk, s);
+        }
+    }
+    return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 0>(p, g, wpk, s);
+}
+
+template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC>
+static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s) {
     constexpr int REC = CK * 4 + 16;
     constexpr int NSTAGE = NLW ? 64 * NLW : 64 * NW;
     const int nrec = g.NIMG * g.PH * g.PW;
-    if ((nrec * (CK / 8) + NSTAGE - 1) / NSTAGE > MAXT) {
+    if (!VEC && (nrec * (CK / 8) + NSTAGE - 1) / NSTAGE > MAXT) {
         set_error("conv_f16s: staging tasks exceed MAXT");
         return CF_ERR_ARG;
     }
@@ -388,7 +493,7 @@ static int launch_f16s(const ConvParams& p, F16sGeom g, const _Float16* wpk, hip
         set_error("conv_f16s: LDS tile too large");
         return CF_ERR_ARG;
     }
-    auto kern = conv_f16s_kernel<KHW, CK, WM, NTW, MAXT, NLW, NW>;
+    auto kern = conv_f16s_kernel<KHW, CK, WM, NTW, MAXT, NLW, NW, VEC>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
