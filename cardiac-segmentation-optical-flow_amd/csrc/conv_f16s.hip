@@ -44,7 +44,13 @@ struct F16sGeom {
     int tiles_x, tiles_y, bgroups;
     int nchunk;
     int NQ;                  // vector staging: 16-byte column quads per patch row (0: scalar staging)
+    // magic multipliers floor(2^32/d)+1 for the index decodes (exact for n < 2^32/d; d == 1 handled apart): the kernel's setup was
+    // ~8k ticks of integer division sequences, a tenth of a 4-chunk workgroup's life
+    unsigned m_tx, m_ty, m_percg, m_phnq, m_nq, m_nrec, m_phpw, m_pw, m_thtw, m_tw;
 };
+
+__host__ __device__ inline unsigned f16s_magic(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
+__device__ __forceinline__ int fdiv(int n, int d, unsigned m) { return d <= 1 ? n : (int)__umulhi((unsigned)n, m); }
 
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     x = __builtin_amdgcn_fmed3f(x, -60000.f, 60000.f);  // one v_med3_f32: keeps huge inputs finite in fp16
@@ -84,10 +90,10 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
         int xcd = bid & 7, qn = nb >> 3, rn = nb & 7;
         bid = ((xcd < rn) ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
     }
-    const int tx = bid % g.tiles_x;
-    int t2 = bid / g.tiles_x;
-    const int ty = t2 % g.tiles_y;
-    const int bg = t2 / g.tiles_y;
+    int t2 = fdiv(bid, g.tiles_x, g.m_tx);
+    const int tx = bid - t2 * g.tiles_x;
+    const int bg = fdiv(t2, g.tiles_y, g.m_ty);
+    const int ty = t2 - bg * g.tiles_y;
     const int x0 = tx * g.TW, y0 = ty * g.TH, b0 = bg * g.NIMG;
     const int HW = p.H * p.W;
     const int HoWo = p.Ho * p.Wo;
@@ -118,12 +124,12 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
         t_g8[t] = 0;
         if (!stages) continue;
         int task = stid + t * NSTAGE;
-        int grp = task / nrec;
+        int grp = fdiv(task, nrec, g.m_nrec);
         int pr = task - grp * nrec;
         if (grp < NG) {
-            int img = pr / (g.PH * g.PW);
+            int img = fdiv(pr, g.PH * g.PW, g.m_phpw);
             int q = pr - img * (g.PH * g.PW);
-            int py = q / g.PW, px = q - py * g.PW;
+            int py = fdiv(q, g.PW, g.m_pw), px = q - py * g.PW;
             int iy = iy_org + py * g.pstep, ix = ix_org + px * g.pstep;
             int b = b0 + img;
             t_lds[t] = pr * REC + grp * 16;
@@ -189,12 +195,12 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
         constexpr int NCG = CK / 4;
         const int xq0 = ix_org & ~3;
         const int per_cg = g.NIMG * g.PH * g.NQ;
-        const int cg = tid / per_cg;
+        const int cg = fdiv(tid, per_cg, g.m_percg);
         int r = tid - cg * per_cg;
         if (cg < NCG) {
-            const int img = r / (g.PH * g.NQ);
+            const int img = fdiv(r, g.PH * g.NQ, g.m_phnq);
             r -= img * (g.PH * g.NQ);
-            const int py = r / g.NQ, q = r - py * g.NQ;
+            const int py = fdiv(r, g.NQ, g.m_nq), q = r - py * g.NQ;
             const int iy = iy_org + py, xq = xq0 + 4 * q, b = b0 + img;
             const int pxp = xq - ix_org;                                  // patch column of the quad's first pixel (may be < 0)
 #pragma unroll
@@ -266,6 +272,11 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     // =================================================================================================================
     // MFMA role
     // =================================================================================================================
+    // the first chunk's loads leave before the (division-heavy) output-coordinate setup below, which then overlaps their latency
+    float stg0[MAXT][8];   // dead (eliminated) in the VEC instantiations
+    f32x4v stgv[4];
+    if (VEC) issue_loads_v(0, stgv);
+    else if (NLW == 0) issue_loads(0, stg0);
     // ---- per-lane B-fragment record offsets and output coordinates of this wave's n-tiles
     int b_rec[NTW];
     bool o_ok[NTW];
@@ -273,9 +284,9 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         int pidx = (ngrp * NTW + nt) * 32 + l31;
-        int img = pidx / (g.TH * g.TW);
+        int img = fdiv(pidx, g.TH * g.TW, g.m_thtw);
         int q = pidx - img * (g.TH * g.TW);
-        int tyy = q / g.TW, txx = q - tyy * g.TW;
+        int tyy = fdiv(q, g.TW, g.m_tw), txx = q - tyy * g.TW;
         bool in_tile = img < g.NIMG;
         if (!in_tile) { img = 0; tyy = 0; txx = 0; }
         b_rec[nt] = ((img * g.PH + tyy * g.ostep) * g.PW + txx * g.ostep) * REC + half * 16;
@@ -308,10 +319,6 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
         aL[slot] = wc[64];
     };
 
-    float stg0[MAXT][8];   // dead (eliminated) in the VEC instantiations
-    f32x4v stgv[4];
-    if (VEC) issue_loads_v(0, stgv);
-    else if (NLW == 0) issue_loads(0, stg0);
 #pragma unroll
     for (int sidx = 0; sidx < D; ++sidx) load_a(0, sidx, sidx % R);
     if (VEC) write_stage_v(0, stgv);
@@ -362,25 +369,82 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     float ssum[16], ssq[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
+    // The epilogue is written as separate compact phases (scale+bias, ONE uniform switch over the activation, residual+store):
+    // with the activation switch inside the per-element code the unrolled epilogue was ~40 KB of instructions, of which each
+    // workgroup executes a sparse path once -- time stamps showed 28-34k ticks (a third of a 64-channel workgroup's life) spent
+    // there, on instruction fetch.
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float bv = 0.f;
+        if (p.bias && co < p.Cout) bv = p.bias[p.scatter2x2 ? (co >> 2) : co];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc1[nt][r] = p.alpha * acc1[nt][r] + bv;
+    }
+    switch (p.act) {   // workgroup-uniform
+        case CF_ACT_GELU:
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc1[nt][r] = act_apply(acc1[nt][r], CF_ACT_GELU);
+                    __builtin_amdgcn_sched_barrier(0);   // one element at a time: these cold paths must not set the kernel's register count
+                }
+            break;
+        case CF_ACT_RELU:
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc1[nt][r] = act_apply(acc1[nt][r], CF_ACT_RELU);
+                    __builtin_amdgcn_sched_barrier(0);   // one element at a time: these cold paths must not set the kernel's register count
+                }
+            break;
+        case CF_ACT_LRELU:
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc1[nt][r] = act_apply(acc1[nt][r], CF_ACT_LRELU);
+                    __builtin_amdgcn_sched_barrier(0);   // one element at a time: these cold paths must not set the kernel's register count
+                }
+            break;
+        case CF_ACT_TANH:
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc1[nt][r] = act_apply(acc1[nt][r], CF_ACT_TANH);
+                    __builtin_amdgcn_sched_barrier(0);   // one element at a time: these cold paths must not set the kernel's register count
+                }
+            break;
+        case CF_ACT_SIGMOID:
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc1[nt][r] = act_apply(acc1[nt][r], CF_ACT_SIGMOID);
+                    __builtin_amdgcn_sched_barrier(0);   // one element at a time: these cold paths must not set the kernel's register count
+                }
+            break;
+        default: break;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (co >= p.Cout) continue;
-        float bv = 0.f;
         long ochan;
         if (p.scatter2x2) {
             const int cr = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
-            if (p.bias) bv = p.bias[cr];
             ochan = (long)cr * (4L * HoWo) + (long)dy * (2 * p.Wo) + dx;
         } else {
-            if (p.bias) bv = p.bias[co];
             ochan = (long)co * HoWo;
         }
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
             if (!o_ok[nt]) continue;
-            float v = act_apply(p.alpha * acc1[nt][r] + bv, p.act);
-            if (p.res) v += p.res[r_off[nt] + (long)co * HoWo];
+            float v = acc1[nt][r];
+            if (p.res) v += p.res[r_off[nt] + (long)co * HoWo];   // rare (SingleConv / Linear residuals)
             p.out[o_off[nt] + ochan] = v;
             ssum[r] += v;
             ssq[r] += v * v;
@@ -484,6 +548,20 @@ static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, h
     constexpr int REC = CK * 4 + 16;
     constexpr int NSTAGE = NLW ? 64 * NLW : 64 * NW;
     const int nrec = g.NIMG * g.PH * g.PW;
+    g.m_tx = f16s_magic(g.tiles_x);
+    g.m_ty = f16s_magic(g.tiles_y);
+    g.m_percg = f16s_magic(g.NIMG * g.PH * g.NQ);
+    g.m_phnq = f16s_magic(g.PH * g.NQ);
+    g.m_nq = f16s_magic(g.NQ);
+    g.m_nrec = f16s_magic(nrec);
+    g.m_phpw = f16s_magic(g.PH * g.PW);
+    g.m_pw = f16s_magic(g.PW);
+    g.m_thtw = f16s_magic(g.TH * g.TW);
+    g.m_tw = f16s_magic(g.TW);
+    if ((long)g.tiles_x * g.tiles_y * g.bgroups >= (1L << 31) / (g.tiles_x > g.tiles_y ? g.tiles_x : g.tiles_y)) {
+        set_error("conv_f16s: grid too large for the index decode");
+        return CF_ERR_ARG;
+    }
     if (!VEC && (nrec * (CK / 8) + NSTAGE - 1) / NSTAGE > MAXT) {
         set_error("conv_f16s: staging tasks exceed MAXT");
         return CF_ERR_ARG;
