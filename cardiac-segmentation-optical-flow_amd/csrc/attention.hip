@@ -105,6 +105,194 @@ __global__ void __launch_bounds__(256) attention_cf_kernel(const float* __restri
         }
 }
 
+
+// =====================================================================================================================
+// f16 hi/lo-split variant (head dims 16, 32, 64): the same orientation and online softmax, but both products run on
+// v_mfma_f32_32x32x16_f16 with the 3-term split of conv_f16s.hip (x = hi + lo in fp16, a.b ~ al.bh + ah.bl + ah.bh, fp32
+// accumulation): 24 f16 MFMAs of 32 cycles per 32-key block instead of 64 fp32 MFMAs of 64 cycles.  The accumulator-as-operand
+// trick survives: for k-step s the f16 B operand of lane (q, half h) wants 8 consecutive k-indices, and the contraction order
+// over the keys is free, so k-index j of step s is DEFINED as the key held by accumulator register 8s + j, i.e. key
+// (j & 3) + 8 (j >> 2) + 16 s + 4 h; the V^T fragment of that step is then two 8-byte runs of 4 keys.  K and V tiles are
+// converted once per workgroup while staging (K as [key][hi D | lo D], V transposed as [dd][hi 32 keys | lo 32 keys], record
+// sizes odd multiples of 16 B: conflict-free b128/b64 reads), double buffered with the next block's loads in flight.
+// =====================================================================================================================
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
+    x = __builtin_amdgcn_fmed3f(x, -60000.f, 60000.f);
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+template <int D>
+__global__ void __launch_bounds__(256, 2) attention_cf_f16s_kernel(const float* __restrict__ q, long q_bs, const float* __restrict__ k,
+                                                                  long k_bs, const float* __restrict__ v, long v_bs,
+                                                                  float* __restrict__ out, int heads, int Nq, int Nk, float scale) {
+    constexpr int KS = D / 16;             // k-steps of the score product
+    constexpr int DT = (D + 31) / 32;      // 32-row tiles of O^T
+    constexpr int KREC = 4 * D + 16;       // bytes per key record  [hi D halves | lo D halves | pad]
+    constexpr int VREC = 128 + 16;         // bytes per dd record   [hi 32 keys | lo 32 keys | pad]
+    constexpr int KBUF = 32 * KREC, VBUF = DT * 32 * VREC;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (KBUF + VBUF)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int qblocks = (Nq + 127) / 128;
+    const int qb = blockIdx.x % qblocks;
+    const int bh = blockIdx.x / qblocks;
+    const int h = bh % heads, b = bh / heads;
+    const int q0 = qb * 128 + wave * 32;
+    const bool active = q0 < Nq;  // wave-uniform (Nq % 32 == 0)
+
+    const float* qp = q + (long)b * q_bs + (long)h * D * Nq;
+    const float* kp = k + (long)b * k_bs + (long)h * D * Nk;
+    const float* vp = v + (long)b * v_bs + (long)h * D * Nk;
+
+    // Q^T fragments (pre-scaled), hi / lo: lane (q, half) holds dd = 16 s + 8 half + j
+    h8 qh[KS], ql[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = active ? qp[(long)(16 * s + 8 * half + j) * Nq + q0 + l31] * scale : 0.f;
+            _Float16 a, c;
+            split_h(x, a, c);
+            qh[s][j] = a;
+            ql[s][j] = c;
+        }
+
+    // staging tasks: K -- thread = (key, 8-dd group): 8 coalesced dword loads, one 16-B hi and one 16-B lo write;
+    //                V -- thread = (dd, 8-key group): two dwordx4 loads, one 16-B hi and one 16-B lo write
+    const int k_key = tid & 31, k_g = tid >> 5;             // groups 0..7 (D = 64 uses all)
+    const bool k_task = k_g < D / 8;
+    const int v_dd = tid >> 2, v_g = tid & 3;
+    const bool v_task = v_dd < D;
+    float kst[8];
+    f4 vst[2];
+    auto issue = [&](int kb) {
+        if (k_task)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kst[j] = kp[(long)(8 * k_g + j) * Nk + kb + k_key];
+        if (v_task) {
+            const f4* src = reinterpret_cast<const f4*>(vp + (long)v_dd * Nk + kb + 8 * v_g);
+            vst[0] = src[0];
+            vst[1] = src[1];
+        }
+    };
+    auto stage = [&](int buf) {
+        unsigned char* kb_ = lds + buf * (KBUF + VBUF);
+        unsigned char* vb_ = kb_ + KBUF;
+        if (k_task) {
+            h8 a, c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 x, y;
+                split_h(kst[j], x, y);
+                a[j] = x;
+                c[j] = y;
+            }
+            *reinterpret_cast<h8*>(kb_ + k_key * KREC + k_g * 16) = a;
+            *reinterpret_cast<h8*>(kb_ + k_key * KREC + 2 * D + k_g * 16) = c;
+        }
+        if (v_task) {
+            h8 a, c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 x, y;
+                split_h(vst[j >> 2][j & 3], x, y);
+                a[j] = x;
+                c[j] = y;
+            }
+            *reinterpret_cast<h8*>(vb_ + v_dd * VREC + v_g * 16) = a;
+            *reinterpret_cast<h8*>(vb_ + v_dd * VREC + 64 + v_g * 16) = c;
+        }
+    };
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;  // l_run: this half-wave's partial sum
+
+    issue(0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kb = 0; kb < Nk; kb += 32, buf ^= 1) {
+        const bool more = kb + 32 < Nk;
+        if (more) issue(kb + 32);
+        if (active) {
+            const unsigned char* kb_ = lds + buf * (KBUF + VBUF);
+            const unsigned char* vb_ = kb_ + KBUF;
+            f32x16 sT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sT[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const h8 kh = *reinterpret_cast<const h8*>(kb_ + l31 * KREC + (16 * s + 8 * half) * 2);
+                const h8 kl = *reinterpret_cast<const h8*>(kb_ + l31 * KREC + 2 * D + (16 * s + 8 * half) * 2);
+                sT = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sT, 0, 0, 0);
+                sT = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sT, 0, 0, 0);
+                sT = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sT, 0, 0, 0);
+            }
+            float mx = sT[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sT[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = expf(m_run - m_new);  // 0 on the first block (m_run = -inf)
+            m_run = m_new;
+            float psum = 0.f;
+            h8 ph[2], pl[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = expf(sT[r] - m_new);
+                psum += pv;
+                _Float16 a, c;
+                split_h(pv, a, c);
+                ph[r >> 3][r & 7] = a;
+                pl[r >> 3][r & 7] = c;
+            }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                const unsigned char* vr = vb_ + (dt * 32 + l31) * VREC;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    // keys (j & 3) + 8 (j >> 2) + 16 s + 4 half, j = 0..7: two runs of 4
+                    const h4 a0 = *reinterpret_cast<const h4*>(vr + (16 * s + 4 * half) * 2);
+                    const h4 a1 = *reinterpret_cast<const h4*>(vr + (16 * s + 4 * half + 8) * 2);
+                    const h4 c0 = *reinterpret_cast<const h4*>(vr + 64 + (16 * s + 4 * half) * 2);
+                    const h4 c1 = *reinterpret_cast<const h4*>(vr + 64 + (16 * s + 4 * half + 8) * 2);
+                    const h8 vh = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const h8 vl = __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+    }
+    if (!active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    float* op = out + ((long)b * heads + h) * D * Nq;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int dd = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (dd < D) op[(long)dd * Nq + q0 + l31] = o[dt][r] * inv;
+        }
+}
+
 }  // namespace cf
 
 using namespace cf;
@@ -119,6 +307,18 @@ extern "C" int cf_attention_cf(const float* q, long q_bs, const float* k, long k
     const float scale = (float)(1.0 / sqrt((double)d));
     dim3 grid((unsigned)(B * heads * ((Nq + 127) / 128)));
     hipStream_t s = as_stream(stream);
+    // head dims >= 16 run on the f16 hi/lo-split kernel (CF_ATTN_F32=1 keeps the exact fp32-MFMA kernel); it reads V with 16-byte
+    // loads: 8-key groups must be 16-byte aligned
+    static int f32_only = -1;
+    if (f32_only < 0) { const char* e = getenv("CF_ATTN_F32"); f32_only = e ? atoi(e) : 0; }
+    const bool valign = ((reinterpret_cast<uintptr_t>(v) | (uintptr_t)(v_bs * 4)) & 15) == 0 && (Nk & 7) == 0;
+    if (!f32_only && d >= 16 && valign) {
+        if (d == 16) hipLaunchKernelGGL((attention_cf_f16s_kernel<16>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale);
+        else if (d == 32) hipLaunchKernelGGL((attention_cf_f16s_kernel<32>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale);
+        else hipLaunchKernelGGL((attention_cf_f16s_kernel<64>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale);
+        CF_CHECK_LAUNCH();
+        return CF_OK;
+    }
     switch (d) {
         case 8: hipLaunchKernelGGL((attention_cf_kernel<8>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale); break;
         case 16: hipLaunchKernelGGL((attention_cf_kernel<16>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale); break;
