@@ -322,6 +322,39 @@ def test_conv_f16s_fused_group_norm_statistics(dev, B, Cin, H, W, Cout, k, strid
     check(res, ref, 3e-5, "gn apply on fused statistics")
 
 
+@pytest.mark.parametrize("B,C1,C2,H,W,Cout,groups", [
+    (12, 32, 0, 128, 128, 64, 8),      # 1536 tiles > 1024 resident workgroups: two tiles per workgroup
+    (9, 16, 16, 128, 96, 128, 8),      # cat input, 128-channel (8-wave) workgroups: 864 tiles > 512
+    (40, 16, 0, 64, 64, 32, 32),       # narrow variant, 1280 tiles, InstanceNorm statistics
+    (11, 16, 0, 100, 132, 64, 8),      # ragged tiles (100 rows, 132 columns), uneven tiles per workgroup
+])
+def test_conv_f16s_persistent_multi_tile(dev, B, C1, C2, H, W, Cout, groups):
+    """Layers with more tiles than resident workgroups run the persistent kernel (a workgroup walks several tiles, staging the
+    next tile's first chunk during the current tile's last): values and fused GroupNorm statistics against the exact fp32
+    MFMA kernel and torch."""
+    from cineflow import ops
+    x1 = randn(B, C1, H, W, seed=70)
+    x2 = randn(B, C2, H, W, seed=71) if C2 else None
+    w = randn(Cout, C1 + C2, 3, 3, seed=72) / math.sqrt((C1 + C2) * 9)
+    b = randn(Cout, seed=73)
+    xin = x1 if x2 is None else torch.cat([x1, x2], 1)
+    y = F.conv2d(xin, w, b, padding=1)
+    wpk, ws_ = ops.pack_conv_weight_f16s(w.to(dev))
+    out, stats = ops.conv2d_f16s(x1.to(dev), wpk, ws_, b.to(dev), Cout, 3, 3, 1, (1, 1), x2=None if x2 is None else x2.to(dev),
+                                 stats_groups=groups)
+    check(out, y, 3e-5, "persistent conv")
+    yo = out.cpu().double()
+    want = torch.stack([yo.view(B, groups, -1).sum(-1), (yo ** 2).view(B, groups, -1).sum(-1)], -1)
+    scale = yo.abs().view(B, groups, -1).sum(-1)[..., None] + 1.0
+    rel = float(((stats.cpu().view(B, groups, 2) - want).abs() / scale).max())
+    assert rel <= 2e-6, rel
+    # without statistics and without bias, into a channel slice of a wider tensor
+    big = torch.zeros(B, Cout + 8, H, W, device=dev)
+    ops.conv2d_f16s(x1.to(dev), wpk, ws_, None, Cout, 3, 3, 1, (1, 1), x2=None if x2 is None else x2.to(dev), out=big, out_coff=8)
+    check(big[:, 8:], F.conv2d(xin, w, None, padding=1), 3e-5, "persistent conv, channel slice")
+    assert float(big[:, :8].abs().max()) == 0.0
+
+
 def test_conv_f16s_dynamic_range(dev):
     """tiny and large operands: the weight pre-scaling keeps the lo halves normal; activations lose <= 2^-25 absolute."""
     from cineflow import ops
