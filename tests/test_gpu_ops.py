@@ -323,15 +323,14 @@ def test_conv_f16s_fused_group_norm_statistics(dev, B, Cin, H, W, Cout, k, strid
 
 
 @pytest.mark.parametrize("B,C1,C2,H,W,Cout,groups", [
-    (12, 32, 0, 128, 128, 64, 8),      # 1536 tiles > 1024 resident workgroups: two tiles per workgroup
-    (9, 16, 16, 128, 96, 128, 8),      # cat input, 128-channel (8-wave) workgroups: 864 tiles > 512
+    (12, 32, 0, 128, 128, 64, 8),      # 1536 tiles: more workgroups than fit on the chip at once
+    (9, 16, 16, 128, 96, 128, 8),      # cat input, 128-channel (8-wave) workgroups
     (40, 16, 0, 64, 64, 32, 32),       # narrow variant, 1280 tiles, InstanceNorm statistics
-    (11, 16, 0, 100, 132, 64, 8),      # ragged tiles (100 rows, 132 columns), uneven tiles per workgroup
+    (11, 16, 0, 100, 132, 64, 8),      # ragged tiles (100 rows, 132 columns)
 ])
-def test_conv_f16s_persistent_multi_tile(dev, B, C1, C2, H, W, Cout, groups):
-    """Layers with more tiles than resident workgroups run the persistent kernel (a workgroup walks several tiles, staging the
-    next tile's first chunk during the current tile's last): values and fused GroupNorm statistics against the exact fp32
-    MFMA kernel and torch."""
+def test_conv_f16s_many_tiles(dev, B, C1, C2, H, W, Cout, groups):
+    """Launches with more tiles than resident workgroups (several dispatch rounds, XCD-banded tile order, vector staging at the
+    image borders): values and fused GroupNorm statistics against torch."""
     from cineflow import ops
     x1 = randn(B, C1, H, W, seed=70)
     x2 = randn(B, C2, H, W, seed=71) if C2 else None
@@ -342,7 +341,7 @@ def test_conv_f16s_persistent_multi_tile(dev, B, C1, C2, H, W, Cout, groups):
     wpk, ws_ = ops.pack_conv_weight_f16s(w.to(dev))
     out, stats = ops.conv2d_f16s(x1.to(dev), wpk, ws_, b.to(dev), Cout, 3, 3, 1, (1, 1), x2=None if x2 is None else x2.to(dev),
                                  stats_groups=groups)
-    check(out, y, 3e-5, "persistent conv")
+    check(out, y, 3e-5, "conv")
     yo = out.cpu().double()
     want = torch.stack([yo.view(B, groups, -1).sum(-1), (yo ** 2).view(B, groups, -1).sum(-1)], -1)
     scale = yo.abs().view(B, groups, -1).sum(-1)[..., None] + 1.0
@@ -351,7 +350,7 @@ def test_conv_f16s_persistent_multi_tile(dev, B, C1, C2, H, W, Cout, groups):
     # without statistics and without bias, into a channel slice of a wider tensor
     big = torch.zeros(B, Cout + 8, H, W, device=dev)
     ops.conv2d_f16s(x1.to(dev), wpk, ws_, None, Cout, 3, 3, 1, (1, 1), x2=None if x2 is None else x2.to(dev), out=big, out_coff=8)
-    check(big[:, 8:], F.conv2d(xin, w, None, padding=1), 3e-5, "persistent conv, channel slice")
+    check(big[:, 8:], F.conv2d(xin, w, None, padding=1), 3e-5, "conv, channel slice")
     assert float(big[:, :8].abs().max()) == 0.0
 
 
