@@ -64,7 +64,7 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 // wait for a weight fragment also waited for the staging loads issued before it (ablating those loads made the kernel
 // 19-33 % faster); with separate roles nothing in the MFMA waves ever waits for HBM.
 template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC>
-__global__ void __launch_bounds__(64 * NW + 64 * NLW, NLW ? 5 : (NW == 8 ? 2 : ((NTW <= 2 && MAXT <= 3) ? 4 : 2)))
+__global__ void __launch_bounds__(64 * NW + 64 * NLW, NLW ? 5 : (NW == 8 ? 2 : ((NTW <= 2 && MAXT <= 3) ? 4 : ((NTW == 4 && WM == 4) ? 3 : 2))))
 conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restrict__ wpk) {
     constexpr int KW = (KHW == 9) ? 3 : 1;
     constexpr int KS = CK / 16;            // MFMA k-steps per tap per chunk
@@ -616,8 +616,8 @@ static int f16s_loader_waves() {
     return v;
 }
 
-// CF_F16S_WIDE=0 disables the 128-channel workgroups (8 MFMA waves = 4 m-tiles x 2 n-groups) used for Cout >= 128:
-// the input patch is staged once per 128 output channels instead of once per 64.
+// CF_F16S_WIDE=0 disables the 128-channel workgroups used for Cout % 128 == 0 (the input patch is staged once per 128 output
+// channels instead of once per 64); 1 = automatic choice between the two 128-channel shapes, 2 / 3 force the 4-wave / 8-wave one.
 static int f16s_wide() {
     static int v = -1;
     if (v < 0) {
@@ -705,7 +705,18 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
         *one_sample_per_wg = g.NIMG == 1;
         return CF_OK;
     }
-    if (wide) return k3 ? launch_f16s<9, 16, 4, 2, 2, 0, 8>(p, g, wpk, s) : launch_f16s<1, 32, 4, 2, 2, 0, 8>(p, g, wpk, s);
+    if (wide && k3) {
+        // Two 128-channel shapes.  Four waves, each ONE m-tile x FOUR pixel tiles: a weight fragment feeds 12 MFMAs instead of 6, which
+        // halves the per-wave weight re-reads from L1/L2 -- the resource the time stamps and the persistent-kernel experiment pointed at
+        // (+9-15 % on the 128- and 256-channel layers at 64x64 and above); 168 VGPRs, 3 waves/SIMD.  With few workgroups (32x32 maps)
+        // the 8-wave shape (4 m-tiles x 2 pixel groups, 4 waves/SIMD) keeps more of the chip busy.  CF_F16S_WIDE=2 / 3 force one.
+        const long nwg = (long)g.tiles_x * g.tiles_y * g.bgroups * (p.Cout / 128);
+        const int mode = f16s_wide();
+        const bool four = mode == 2 || (mode == 1 && nwg >= 1024 && g.NIMG == 1);
+        if (four && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 <= 2) return launch_f16s<9, 16, 4, 4, 2, 0, 4>(p, g, wpk, s);
+        return launch_f16s<9, 16, 4, 2, 2, 0, 8>(p, g, wpk, s);
+    }
+    if (wide) return launch_f16s<1, 32, 4, 2, 2, 0, 8>(p, g, wpk, s);
     if (small && f16s_loader_waves() > 0) {
         if (narrow && !s2) return k3 ? launch_f16s<9, 16, 1, 1, 4, 2>(p, g, wpk, s) : launch_f16s<1, 32, 1, 1, 4, 2>(p, g, wpk, s);
         if (s2 && !narrow) return launch_f16s<9, 16, 2, 1, 4, 3>(p, g, wpk, s);
