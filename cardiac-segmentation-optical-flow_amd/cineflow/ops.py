@@ -197,6 +197,23 @@ def pack_conv_weight_f16s(w):
     return x.view(-1), s
 
 
+_zero_pool = {}
+
+
+def _zeroed_stats_ws(n, device):
+    """n doubles of a pool cleared with ONE memset (the convolution's fused GroupNorm statistics accumulate with atomics and need a
+    zero start; a memset per launch was 1.2 % of the step).  Slices are handed out once; an exhausted pool is replaced by a fresh
+    zeroed one (the old one lives as long as its slices do)."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    pool = _zero_pool.get(key)
+    if pool is None or pool[1] + n > pool[0].numel():
+        pool = [torch.zeros(max(n, 1 << 23), dtype=torch.float64, device=device), 0]   # 64 MB
+        _zero_pool[key] = pool
+    ws = pool[0][pool[1]:pool[1] + n]
+    pool[1] += (n + 1) & ~1   # keep 16-byte alignment
+    return ws
+
+
 def conv2d_f16s(x1, wpk, wscale, bias, cout, kh, kw, stride=1, pad=(0, 0), x2=None, act=None, res=None, out=None, out_coff=0, alpha=1.0,
                 stats_groups=None):
     """With stats_groups=G the call returns (out, ws): ws holds the GroupNorm statistics of `out` for group_norm_apply."""
@@ -210,10 +227,10 @@ def conv2d_f16s(x1, wpk, wscale, bias, cout, kh, kw, stride=1, pad=(0, 0), x2=No
     if res is not None:
         assert res.shape == (B, cout, Ho, Wo)
     assert wpk.dtype == torch.float16 and wpk.is_cuda
-    ws = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x1.device) if stats_groups else None
+    ws = _zeroed_stats_ws(2 * B * stats_groups, x1.device) if stats_groups else None
     check(lib().cf_conv2d_f16s(_f32(x1), C1, _opt(x2), C2, wpk.data_ptr(), _opt(bias), _opt(res), _f32(out), out.shape[1], out_coff, B, H, W,
                                cout, kh, kw, stride, pad[0], pad[1], ACT[act], float(alpha) * (2.0 ** -wscale),
-                               None if ws is None else ws.data_ptr(), stats_groups or 0, _stream()), "cf_conv2d_f16s")
+                               None if ws is None else ws.data_ptr(), -stats_groups if stats_groups else 0, _stream()), "cf_conv2d_f16s")
     return (out, ws) if stats_groups else out
 
 

@@ -20,6 +20,7 @@ struct ConvParams {
     int scatter2x2;       // 1: ConvTranspose k2s2 epilogue (GEMM row m = co*4 + dy*2 + dx)
     double* gn_ws;        // optional: accumulate GroupNorm statistics of the OUTPUT (sum, sum of squares per (sample, group))
     int gn_groups;
+    int gn_prezeroed = 0;   // gn_ws is already zero (caller-managed pool)
 };
 
 // validates nothing; callers validate.  Returns CF_OK / CF_ERR_LAUNCH.

@@ -646,7 +646,10 @@ int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
     launch_conv_f16s_impl(p, nullptr, s, &fusable);  // geometry probe only
     ConvParams q = p;
     if (fusable && !p.scatter2x2) {
-        if (hipMemsetAsync(p.gn_ws, 0, sizeof(double) * 2 * (size_t)p.B * p.gn_groups, s) != hipSuccess) { set_error("conv_f16s: memset failed"); return CF_ERR_LAUNCH; }
+        // the fused statistics accumulate with atomics: the workspace must start at zero (gn_prezeroed: the caller hands out slices
+        // of a pool it zeroed with ONE memset -- the per-launch memsets were 1.2 % of the step)
+        if (!p.gn_prezeroed &&
+            hipMemsetAsync(p.gn_ws, 0, sizeof(double) * 2 * (size_t)p.B * p.gn_groups, s) != hipSuccess) { set_error("conv_f16s: memset failed"); return CF_ERR_LAUNCH; }
         return launch_conv_f16s_impl(q, wpk, s, nullptr);
     }
     q.gn_ws = nullptr;
@@ -750,8 +753,8 @@ extern "C" int cf_conv2d_f16s(const float* x1, int C1, const float* x2, int C2, 
     p.C1 = C1; p.C2 = C2; p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride;
     p.pad_h = pad_h; p.pad_w = pad_w; p.Ho = (H + 2 * pad_h - KH) / stride + 1; p.Wo = (W + 2 * pad_w - KW) / stride + 1;
     p.out_ctotal = out_ctotal; p.out_coff = out_coff; p.act = act; p.alpha = alpha; p.scatter2x2 = 0;
-    p.gn_ws = gn_ws; p.gn_groups = gn_groups;
-    CF_REQUIRE(!gn_ws || (gn_groups > 0 && Cout % gn_groups == 0 && out_coff == 0 && out_ctotal == Cout), "bad GroupNorm statistics request");
+    p.gn_ws = gn_ws; p.gn_groups = gn_groups < 0 ? -gn_groups : gn_groups; p.gn_prezeroed = gn_groups < 0;
+    CF_REQUIRE(!gn_ws || (p.gn_groups > 0 && Cout % p.gn_groups == 0 && out_coff == 0 && out_ctotal == Cout), "bad GroupNorm statistics request");
     CF_REQUIRE(p.Ho > 0 && p.Wo > 0, "empty output");
     CF_REQUIRE(conv_f16s_supported(p), "unsupported configuration for the f16-split kernel (3x3 pad 1 or 1x1 pad 0, stride 1/2)");
     return launch_conv_f16s(p, reinterpret_cast<const _Float16*>(wpk), as_stream(stream));

@@ -117,7 +117,9 @@ int cf_conv2d(const float* x1, int C1, const float* x2, int C2, const float* wt,
  * pass alpha * 2^-s as `alpha`.
  * gn_ws (nullable, 2*B*gn_groups doubles): on return it holds the GroupNorm / InstanceNorm statistics (sum, sum of squares
  * per (sample, group)) of the OUTPUT, accumulated in the conv epilogue (or by a statistics pass when a workgroup spans
- * several samples); feed it to cf_group_norm_apply.  Requires a dense output (out_coff 0, out_ctotal == Cout). */
+ * several samples); feed it to cf_group_norm_apply.  Requires a dense output (out_coff 0, out_ctotal == Cout).
+ * A NEGATIVE gn_groups (= -groups) declares that gn_ws already holds zeros (slices of a pool the caller cleared with one
+ * memset): the per-launch memset is skipped. */
 int cf_conv2d_f16s(const float* x1, int C1, const float* x2, int C2, const void* wpk, const float* bias, const float* res,
                    float* out, int out_ctotal, int out_coff, int B, int H, int W, int Cout, int KH, int KW, int stride,
                    int pad_h, int pad_w, int act, float alpha, double* gn_ws, int gn_groups, void* stream);
