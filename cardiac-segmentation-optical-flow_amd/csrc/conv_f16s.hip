@@ -719,13 +719,22 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
         if (four && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 <= 2) return launch_f16s<9, 16, 4, 4, 2, 0, 4>(p, g, wpk, s);
         return launch_f16s<9, 16, 4, 2, 2, 0, 8>(p, g, wpk, s);
     }
-    if (wide) return launch_f16s<1, 32, 4, 2, 2, 0, 8>(p, g, wpk, s);
+    if (wide) {   // 1x1: same choice between the two 128-channel shapes
+        const long nwg = (long)g.tiles_x * g.tiles_y * g.bgroups * (p.Cout / 128);
+        static int k1four = -1;
+        if (k1four < 0) { const char* e = getenv("CF_F16S_K1FOUR"); k1four = e ? atoi(e) : 1; }
+        if (k1four && nwg >= 1024 && g.NIMG == 1 && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 <= 2) return launch_f16s<1, 32, 4, 4, 2, 0, 4>(p, g, wpk, s);
+        return launch_f16s<1, 32, 4, 2, 2, 0, 8>(p, g, wpk, s);
+    }
     if (small && f16s_loader_waves() > 0) {
         if (narrow && !s2) return k3 ? launch_f16s<9, 16, 1, 1, 4, 2>(p, g, wpk, s) : launch_f16s<1, 32, 1, 1, 4, 2>(p, g, wpk, s);
         if (s2 && !narrow) return launch_f16s<9, 16, 2, 1, 4, 3>(p, g, wpk, s);
         if (!narrow) return k3 ? launch_f16s<9, 16, 2, 2, 4, 2>(p, g, wpk, s) : launch_f16s<1, 32, 2, 2, 4, 2>(p, g, wpk, s);
     }
     if (small && narrow && !s2) return k3 ? launch_f16s<9, 16, 1, 1, 2>(p, g, wpk, s) : launch_f16s<1, 32, 1, 1, 2>(p, g, wpk, s);
+    // stride 2 with Cout % 128 == 0: four m-tiles x two pixel tiles per wave -- every weight fragment is loaded once per workgroup and
+    // feeds 6 MFMAs (the 64-channel shape below: loaded twice, 3 MFMAs each)
+    if (small && s2 && !narrow && p.Cout % 128 == 0 && f16s_wide()) return launch_f16s<9, 16, 4, 2, 3>(p, g, wpk, s);
     if (small && s2 && !narrow) return launch_f16s<9, 16, 2, 1, 3>(p, g, wpk, s);
     if (small && !narrow) return k3 ? launch_f16s<9, 16, 2, 2, 2>(p, g, wpk, s) : launch_f16s<1, 32, 2, 2, 2>(p, g, wpk, s);
     if (k3) {
