@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--slices", type=int, default=32, help="cine slices per step and per GPU (B)")
     ap.add_argument("--frames", type=int, default=30, help="frames per cine slice (T)")
     ap.add_argument("--variant", default="video", choices=["video", "raft_config"])
-    ap.add_argument("--seg-chunk", type=int, default=120)
+    ap.add_argument("--seg-chunk", type=int, default=240, help="frames per segmentation U-Net call (240 x 32 ch x 256^2 fp32 stays under the 2 GiB buffer-offset limit of the f16 conv kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", default="f16s", choices=["f16s", "f32"], help="f16s: f16-MFMA hi/lo split (default); f32: exact fp32 MFMA")
     ap.add_argument("--cpu-frames", type=int, default=5)
