@@ -46,6 +46,7 @@ struct F16sGeom {
     int NQ;                  // vector staging: 16-byte column quads per patch row (0: scalar staging)
     // magic multipliers floor(2^32/d)+1 for the index decodes (exact for n < 2^32/d; d == 1 handled apart): the kernel's setup was
     // ~8k ticks of integer division sequences, a tenth of a 4-chunk workgroup's life
+    int PWR, pwh, kx1, kx2;  // LDS row pitch in records and the record offsets of taps kx = 1, 2 (stride 2: columns de-interleaved by parity)
     unsigned m_tx, m_ty, m_percg, m_phnq, m_nq, m_nrec, m_phpw, m_pw, m_thtw, m_tw;
 };
 
@@ -99,7 +100,7 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     const int HoWo = p.Ho * p.Wo;
     const int iy_org = y0 * p.stride - p.pad_h, ix_org = x0 * p.stride - p.pad_w;
     const int nrec = g.NIMG * g.PH * g.PW;
-    const int buf_bytes = nrec * REC;
+    const int buf_bytes = g.NIMG * g.PH * g.PWR * REC;
     const bool do_stats = p.gn_ws != nullptr;
 
     // =================================================================================================================
@@ -132,7 +133,8 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
             int py = fdiv(q, g.PW, g.m_pw), px = q - py * g.PW;
             int iy = iy_org + py * g.pstep, ix = ix_org + px * g.pstep;
             int b = b0 + img;
-            t_lds[t] = pr * REC + grp * 16;
+            const int pxs = g.pwh ? (px >> 1) + (px & 1) * g.pwh : px;    // stride 2: even columns first, then the odd ones
+            t_lds[t] = (((img * g.PH + py) * g.PWR) + pxs) * REC + grp * 16;
             t_g8[t] = grp * 8;
             if (b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
                 const unsigned sp = (unsigned)(iy * p.W + ix);
@@ -189,58 +191,71 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     // patch are simply not written.  Host checks: stride 1, W % 4 == 0, 16-byte aligned tensors, one task per thread.
     typedef float f32x4v __attribute__((ext_vector_type(4)));
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-    unsigned v_o1 = OOB, v_o2 = OOB, v_c4 = 0, v_mask = 0;
-    int v_lds = 0;
+    constexpr int VT = VEC ? VEC : 1;                                     // vector tasks per staging thread
+    unsigned v_o1[VT], v_o2[VT], v_c4[VT], v_mask[VT];
+    int v_lds[VT];
+#pragma unroll
+    for (int t = 0; t < VT; ++t) { v_o1[t] = OOB; v_o2[t] = OOB; v_c4[t] = 0; v_mask[t] = 0; v_lds[t] = 0; }
     if (VEC) {
         constexpr int NCG = CK / 4;
         const int xq0 = ix_org & ~3;
         const int per_cg = g.NIMG * g.PH * g.NQ;
-        const int cg = fdiv(tid, per_cg, g.m_percg);
-        int r = tid - cg * per_cg;
-        if (cg < NCG) {
-            const int img = fdiv(r, g.PH * g.NQ, g.m_phnq);
-            r -= img * (g.PH * g.NQ);
-            const int py = fdiv(r, g.NQ, g.m_nq), q = r - py * g.NQ;
-            const int iy = iy_org + py, xq = xq0 + 4 * q, b = b0 + img;
-            const int pxp = xq - ix_org;                                  // patch column of the quad's first pixel (may be < 0)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v_mask |= ((unsigned)(pxp + k) < (unsigned)g.PW) ? (1u << k) : 0u;
-            v_lds = ((img * g.PH + py) * g.PW + pxp) * REC + cg * 8;
-            v_c4 = cg * 4;
-            if (b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)xq < (unsigned)p.W) {
-                const unsigned sp = (unsigned)(iy * p.W + xq);
-                v_o1 = ((unsigned)b * p.C1 * HW + sp) * 4u;
-                v_o2 = ((unsigned)b * p.C2 * HW + sp) * 4u;
+        for (int t = 0; t < VT; ++t) {
+            const int task = tid + t * NSTAGE;
+            const int cg = fdiv(task, per_cg, g.m_percg);
+            int r = task - cg * per_cg;
+            if (cg < NCG) {
+                const int img = fdiv(r, g.PH * g.NQ, g.m_phnq);
+                r -= img * (g.PH * g.NQ);
+                const int py = fdiv(r, g.NQ, g.m_nq), q = r - py * g.NQ;
+                const int iy = iy_org + py, xq = xq0 + 4 * q, b = b0 + img;
+                const int pxp = xq - ix_org;                              // patch column of the quad's first pixel (may be < 0)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v_mask[t] |= ((unsigned)(pxp + k) < (unsigned)g.PW) ? (1u << k) : 0u;
+                v_lds[t] = ((img * g.PH + py) * g.PWR + pxp) * REC + cg * 8;
+                v_c4[t] = cg * 4;
+                if (b < p.B && (unsigned)iy < (unsigned)p.H && (unsigned)xq < (unsigned)p.W) {
+                    const unsigned sp = (unsigned)(iy * p.W + xq);
+                    v_o1[t] = ((unsigned)b * p.C1 * HW + sp) * 4u;
+                    v_o2[t] = ((unsigned)b * p.C2 * HW + sp) * 4u;
+                }
             }
         }
     }
-    auto issue_loads_v = [&](int chunk, f32x4v (&stg)[4]) {
+    auto issue_loads_v = [&](int chunk, f32x4v (&stg)[VT][4]) {
         const int c0 = chunk * CK;
         const bool in1 = c0 < p.C1;
         const unsigned cb = (unsigned)(in1 ? c0 : c0 - p.C1);
-        const unsigned v0 = (in1 ? v_o1 : v_o2) + (cb + v_c4) * HW4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned off = v0 + (unsigned)j * HW4;
-            stg[j] = in1 ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, 0, 0))
-                         : __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, 0, 0));
-        }
-    };
-    auto write_stage_v = [&](int chunk, const f32x4v (&stg)[4]) {
-        unsigned char* base = lds + (chunk & 1) * buf_bytes + v_lds;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!((v_mask >> k) & 1u)) continue;
-            f16x4 hi, lo;
+        for (int t = 0; t < VT; ++t) {
+            const unsigned v0 = (in1 ? v_o1[t] : v_o2[t]) + (cb + v_c4[t]) * HW4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                _Float16 h, l;
-                split_f16(stg[j][k], h, l);
-                hi[j] = h;
-                lo[j] = l;
+                const unsigned off = v0 + (unsigned)j * HW4;
+                stg[t][j] = in1 ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, 0, 0))
+                                : __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, 0, 0));
             }
-            *reinterpret_cast<f16x4*>(base + k * REC) = hi;
-            *reinterpret_cast<f16x4*>(base + k * REC + CK * 2) = lo;
+        }
+    };
+    auto write_stage_v = [&](int chunk, const f32x4v (&stg)[VT][4]) {
+#pragma unroll
+        for (int t = 0; t < VT; ++t) {
+            unsigned char* base = lds + (chunk & 1) * buf_bytes + v_lds[t];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!((v_mask[t] >> k) & 1u)) continue;
+                f16x4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    _Float16 h, l;
+                    split_f16(stg[t][j][k], h, l);
+                    hi[j] = h;
+                    lo[j] = l;
+                }
+                *reinterpret_cast<f16x4*>(base + k * REC) = hi;
+                *reinterpret_cast<f16x4*>(base + k * REC + CK * 2) = lo;
+            }
         }
     };
 
@@ -274,29 +289,19 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     // =================================================================================================================
     // the first chunk's loads leave before the (division-heavy) output-coordinate setup below, which then overlaps their latency
     float stg0[MAXT][8];   // dead (eliminated) in the VEC instantiations
-    f32x4v stgv[4];
+    f32x4v stgv[VT][4];
     if (VEC) issue_loads_v(0, stgv);
     else if (NLW == 0) issue_loads(0, stg0);
     // ---- per-lane B-fragment record offsets and output coordinates of this wave's n-tiles
     int b_rec[NTW];
-    bool o_ok[NTW];
-    long o_off[NTW], r_off[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         int pidx = (ngrp * NTW + nt) * 32 + l31;
         int img = fdiv(pidx, g.TH * g.TW, g.m_thtw);
         int q = pidx - img * (g.TH * g.TW);
         int tyy = fdiv(q, g.TW, g.m_tw), txx = q - tyy * g.TW;
-        bool in_tile = img < g.NIMG;
-        if (!in_tile) { img = 0; tyy = 0; txx = 0; }
-        b_rec[nt] = ((img * g.PH + tyy * g.ostep) * g.PW + txx * g.ostep) * REC + half * 16;
-        int b = b0 + img, oy = y0 + tyy, ox = x0 + txx;
-        o_ok[nt] = in_tile && b < p.B && oy < p.Ho && ox < p.Wo;
-        if (p.scatter2x2)
-            o_off[nt] = ((long)b * p.out_ctotal + p.out_coff) * (4L * HoWo) + (long)(2 * oy) * (2 * p.Wo) + 2 * ox;
-        else
-            o_off[nt] = ((long)b * p.out_ctotal + p.out_coff) * (long)HoWo + (long)oy * p.Wo + ox;
-        r_off[nt] = (long)b * p.Cout * HoWo + (long)oy * p.Wo + ox;
+        if (img >= g.NIMG) { img = 0; tyy = 0; txx = 0; }
+        b_rec[nt] = ((img * g.PH + tyy * g.ostep) * g.PWR + txx * (g.pwh ? 1 : g.ostep)) * REC + half * 16;
     }
 
     f32x16 acc1[NTW];
@@ -341,7 +346,7 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const int toff = ((tap / KW) * g.PW + (tap % KW)) * REC;
+            const int toff = ((tap / KW) * g.PWR + (tap % KW == 0 ? 0 : (tap % KW == 1 ? g.kx1 : g.kx2))) * REC;
             const f16x8 ah = aH[step % R], al = aL[step % R];
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
@@ -429,6 +434,30 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
             break;
         default: break;
     }
+    // output coordinates are derived here rather than ahead of the main loop: 4*NTW fewer registers live across it
+    bool o_ok[NTW];
+    long o_off[NTW], r_off[NTW];
+    auto out_coords = [&]() {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            int pidx = (ngrp * NTW + nt) * 32 + l31;
+            asm volatile("" : "+v"(pidx));                   // keep the address math below the main loop
+            int img = fdiv(pidx, g.TH * g.TW, g.m_thtw);
+            int q = pidx - img * (g.TH * g.TW);
+            int tyy = fdiv(q, g.TW, g.m_tw), txx = q - tyy * g.TW;
+            bool in_tile = img < g.NIMG;
+            if (!in_tile) { img = 0; tyy = 0; txx = 0; }
+            int b = b0 + img, oy = y0 + tyy, ox = x0 + txx;
+            o_ok[nt] = in_tile && b < p.B && oy < p.Ho && ox < p.Wo;
+            if (p.scatter2x2)
+                o_off[nt] = ((long)b * p.out_ctotal + p.out_coff) * (4L * HoWo) + (long)(2 * oy) * (2 * p.Wo) + 2 * ox;
+            else
+                o_off[nt] = ((long)b * p.out_ctotal + p.out_coff) * (long)HoWo + (long)oy * p.Wo + ox;
+            r_off[nt] = (long)b * p.Cout * HoWo + (long)oy * p.Wo + ox;
+        }
+    };
+    {
+    out_coords();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -449,6 +478,7 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
             ssum[r] += v;
             ssq[r] += v * v;
         }
+    }
     }
     if (do_stats) {
         auto xreduce = [&](float (&v)[16]) {
@@ -512,6 +542,12 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+static int f16s_deint() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CF_F16S_DEINT"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 // CF_F16S_VEC=0 keeps the scalar (one dword per lane and channel) staging everywhere
 static int f16s_vec() {
     static int v = -1;
@@ -535,10 +571,11 @@ static int launch_f16s(const ConvParams& p, F16sGeom g, const _Float16* wpk, hip
         ((reinterpret_cast<uintptr_t>(p.x1) | reinterpret_cast<uintptr_t>(p.x2)) & 15) == 0) {
         const int a = (-p.pad_w) & 3;                       // ix_org mod 4 (tile origins are multiples of 4)
         const int nq = ((a + g.PW - 1) >> 2) + 1;
-        if ((CK / 4) * g.NIMG * g.PH * nq <= 64 * NW) {
-            g.NQ = nq;
-            return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 1>(p, g, wpk, s);
-        }
+        const int tasks = (CK / 4) * g.NIMG * g.PH * nq;
+        g.NQ = nq;
+        if (tasks <= 64 * NW) return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 1>(p, g, wpk, s);
+        // (two tasks per thread for the (2 TH + 1) x (2 TW + 1) patches of the stride-2 shapes: measured equal or 2 % slower, not built)
+        g.NQ = 0;
     }
     return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 0>(p, g, wpk, s);
 }
@@ -566,7 +603,7 @@ static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, h
         set_error("conv_f16s: staging tasks exceed MAXT");
         return CF_ERR_ARG;
     }
-    const size_t lds_bytes = (size_t)2 * nrec * REC;
+    const size_t lds_bytes = (size_t)2 * g.NIMG * g.PH * g.PWR * REC;
     if (lds_bytes > 160 * 1024) {
         set_error("conv_f16s: LDS tile too large");
         return CF_ERR_ARG;
@@ -700,6 +737,11 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
         const int nstage = ws ? ((s2 && !narrow) ? 192 : 128) : (wide ? 512 : 256);
         while (g.NIMG > 1 && (g.NIMG * g.PH * g.PW * (CK / 8) + nstage - 1) / nstage > maxt) --g.NIMG;
     }
+    // Stride 2: output-pixel lanes read every second input column; with plain row-major records (80 B apart) their 160-byte lane
+    // stride lands 16 lanes on 8 of the 16 LDS slots (2-way conflicts on every B-fragment read).  The patch rows are therefore stored
+    // de-interleaved -- even columns, then odd columns -- so a tap's 32 lanes read consecutive records again.
+    g.PWR = g.PW; g.pwh = 0; g.kx1 = 1; g.kx2 = 2;
+    if (s2 && f16s_deint()) { g.pwh = (g.PW + 1) / 2; g.PWR = 2 * g.pwh; g.kx1 = g.pwh; g.kx2 = 1; }
     g.tiles_x = (p.Wo + g.TW - 1) / g.TW;
     g.tiles_y = (p.Ho + g.TH - 1) / g.TH;
     g.bgroups = (p.B + g.NIMG - 1) / g.NIMG;

@@ -22,7 +22,7 @@ def shape_key(name, args, kw):
         cout, kh, kw_ = args[4], args[5], args[6]
         x2 = kw.get("x2")
         c2 = 0 if x2 is None else x2.shape[1]
-        st = kw.get("stride", 1)
+        st = args[7] if len(args) > 7 else kw.get("stride", 1)
         B, C1, H, W = x1.shape
         flop = 2.0 * B * (H // st) * (W // st) * cout * (C1 + c2) * kh * kw_
         return "%s B%d C%d+%d %dx%d -> %d k%d s%d%s%s" % (name, B, C1, c2, H, W, cout, kh, st, " act=" + str(kw.get("act")) if kw.get("act") else "",
