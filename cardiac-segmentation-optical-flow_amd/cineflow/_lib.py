@@ -67,6 +67,18 @@ SIGNATURES = {
     "cf_cc_sweep": [P, I, I, I, P, P],
     "cf_cc_count": [P, P, L, P],
     "cf_cc_remove": [P, P, P, L, I, DBL, DBL, P],
+    "cf_nonzero_mask": [P, I, L, P, P],
+    "cf_fill_holes": [P, P, P, I, I, I, I, P],
+    "cf_mask_bbox": [P, I, I, I, P, P],
+    "cf_spline3_resample_axis": [P, P, L, I, L, I, P],
+    "cf_slab_minmax_chunks": [I, I, I, L],
+    "cf_slab_minmax": [P, I, I, I, L, P, P, P],
+    "cf_slab_clip_to_f32": [P, P, I, I, I, L, P, P],
+    "cf_masked_moments": [P, P, L, I, F, F, P, P],
+    "cf_normalize": [P, P, L, I, F, F, F, F, I, P],
+    "cf_nan_to_zero": [P, L, P],
+    "cf_assign_where_ge": [P, P, L, F, F, P],
+    "cf_seg_outside_mask": [P, P, I, L, F, P],
     "cf_profile_enable": [I],
     "cf_profile_reset": [],
     "cf_profile_read": [I, P, P, P],

@@ -78,20 +78,29 @@ class CineTrainer:
 
     # -- nnUNetTrainer.py:571-597 preprocess_patient(list_of_files) -> (data[C,Z,Y,X], seg, properties)
     def preprocess_patient(self, input_files):
-        vols, props = [], None
-        for f in input_files:
-            a, pr = read_nifti(f)
-            vols.append(a.astype(np.float32))
-            props = props or pr
-        data = np.stack(vols, 0)
-        properties = dict(props)
-        properties.update(original_size_of_raw_data=np.array(data.shape[1:]), original_spacing=np.array(props["itk_spacing"])[::-1],
-                          list_of_data_files=list(input_files), crop_bbox=None, size_after_cropping=np.array(data.shape[1:]),
-                          size_after_resampling=np.array(data.shape[1:]), spacing_after_resampling=np.array(props["itk_spacing"])[::-1])
-        for c in range(data.shape[0]):
-            m, s = data[c].mean(), data[c].std()
-            data[c] = (data[c] - m) / (s + 1e-8)
-        return data, None, properties
+        """Crop to non-zero, resample to the stage's spacing and normalise on the device (cineflow.preprocessing), driven by the
+        same plan entries as the reference: preprocessor_name (default PreprocessorFor2D -- the fork's networks are 2-D),
+        normalization_schemes, use_mask_for_norm, transpose_forward, dataset_properties.intensityproperties and
+        plans_per_stage[stage].current_spacing (absent: the case keeps its own spacing)."""
+        from . import preprocessing as P
+        plans = self.plans
+        nmod = plans["num_modalities"]
+        as_int_keys = lambda d, default: {int(k): v for k, v in (d or {c: default for c in range(nmod)}).items()}   # noqa: E731  (JSON keys are strings)
+        schemes = as_int_keys(plans.get("normalization_schemes"), "nonCT")
+        use_mask = as_int_keys(plans.get("use_mask_for_norm"), False)
+        ip = (plans.get("dataset_properties") or {}).get("intensityproperties")
+        ip = None if ip is None else {int(k): v for k, v in ip.items()}
+        name = plans.get("preprocessor_name") or "PreprocessorFor2D"
+        cls = getattr(P, name, None)
+        assert cls is not None, "Could not find preprocessor %s in cineflow.preprocessing" % name
+        pre = cls(schemes, use_mask, list(plans["transpose_forward"]), ip)
+        stages = plans.get("plans_per_stage")
+        if stages:
+            st = stages[str(plans.get("stage", 0))] if isinstance(stages, dict) and str(plans.get("stage", 0)) in stages else stages[plans.get("stage", 0)]
+            return pre.preprocess_test_case(list(input_files), np.array(st["current_spacing"], dtype=float))
+        data, seg, properties = P.ImageCropper.crop_from_list_of_files(list(input_files))
+        own = np.array(properties["original_spacing"], dtype=float)[list(plans["transpose_forward"])]
+        return pre.preprocess_arrays(data, seg, properties, own)
 
     # -- nnUNetTrainer.py:637-679
     def predict_preprocessed_data_return_seg_and_softmax(self, data, do_mirroring=True, mirror_axes=None, use_sliding_window=True,

@@ -218,6 +218,36 @@ int cf_cc_remove(uint8_t* image, const int* labels, const int* counts, long n, i
 int cf_resize3d(const float* src, float* dst, int N, int X, int Y, int Z, int X2, int Y2, int Z2, int linear_x, int linear_y,
                 int linear_z, void* stream);
 
+/* ---------------------------------------------------------------- test-time preprocessing (the step before the path)
+ * create_nonzero_mask, nnunet/preprocessing/cropping.py:25-32: mask[v] = any_c data[c][v] != 0 (uint8 [V]). */
+int cf_nonzero_mask(const float* data, int C, long V, uint8_t* mask, void* stream);
+/* scipy.ndimage.binary_fill_holes of cropping.py:31 -- `labels` are the converged cf_cc_init/cf_cc_sweep labels of the BACKGROUND
+ * (class value 0) of `mask`; background components without a voxel on the array border become 1.  touch: int32 [D*H*W] scratch.
+ * ndim 3: all six faces are border; ndim 2 (D == 1): the four edges. */
+int cf_fill_holes(uint8_t* mask, const int* labels, int* touch, int D, int H, int W, int ndim, void* stream);
+/* get_bbox_from_mask, cropping.py:47-55: bbox (device int32 [6]) = {min z, max z, min y, max y, min x, max x} over mask != 0
+ * (inclusive maxima; {INT_MAX, -1, ...} for an empty mask).  Synchronises the stream once for its initialisation copy. */
+int cf_mask_bbox(const uint8_t* mask, int D, int H, int W, int* bbox, void* stream);
+/* One axis of skimage.transform.resize(order=3, mode='edge', anti_aliasing=False) (= scipy.ndimage.zoom(order=3, mode='nearest',
+ * grid_mode=True)) as used by resample_data_or_seg, preprocessing.py:111-200: src fp64 [outer][n][inner] -> dst [outer][m][inner]. */
+int cf_spline3_resample_axis(const double* src, double* dst, long outer, int n, long inner, int m, void* stream);
+/* resize's clip=True: range of every slab (c, s) of x fp64 [C][A][S][B] -> minmax fp64 [C*S][2]; then y (same layout, resampled
+ * A and B) clipped to its slab's range (minmax may be NULL: no clipping) and rounded to fp32. */
+int cf_slab_minmax_chunks(int C, int A, int S, long B);   /* k: `partial` of cf_slab_minmax is fp64 [C*S][k][2] scratch */
+int cf_slab_minmax(const double* x, int C, int A, int S, long B, double* minmax, double* partial, void* stream);
+int cf_slab_clip_to_f32(const double* y, float* out, int C, int A, int S, long B, const double* minmax, void* stream);
+/* Intensity normalisation, preprocessing.py:274-320.  cf_masked_moments: out3 (device fp64) = {sum, sum of squares, count} over the
+ * voxels with seg >= 0 (seg may be NULL: all) and, when use_range, lo < x < hi.  cf_normalize, in place:
+ * x = ((clip ? clamp(x, lo, hi) : x) - sub) / div, then 0 where zero_outside and seg < 0. */
+int cf_masked_moments(const float* x, const float* seg, long n, int use_range, float lo, float hi, double* out3, void* stream);
+int cf_normalize(float* x, const float* seg, long n, int clip, float lo, float hi, float sub, float div, int zero_outside, void* stream);
+/* preprocessing.py:251 `data[np.isnan(data)] = 0`, in place */
+int cf_nan_to_zero(float* x, long n, void* stream);
+/* batchgenerators resize_segmentation (orders > 0): dst[i] = value where the resized indicator src[i] >= thr */
+int cf_assign_where_ge(float* dst, const float* src, long n, float thr, float value, void* stream);
+/* cropping.py:128-135: seg [C][V] gets `label` where seg == 0 and mask [V] == 0 (a zero-filled seg yields the created one) */
+int cf_seg_outside_mask(float* seg, const uint8_t* mask, int C, long V, float label, void* stream);
+
 /* ---------------------------------------------------------------- measurement hooks (bench.py only; no reference analogue)
  * cf_profile_enable(n): pre-create n event pairs and time every conv / CorrVolume launch with a (start, stop) pair that
  * brackets exactly that kernel on its own stream (hipExtLaunchKernelGGL); 0 disables.  Kernel ids:

@@ -225,6 +225,22 @@ def test_predict_from_folder_end_to_end(dev, tmp_path):
         pp, _ = read_nifti(str(tmp_path / "out2" / "patient002" / "Segmentation" / (case + ".nii.gz")))
         ref = OO.remove_all_but_the_largest_connected_component(raw.copy(), [1, 2, 3], 1.5 * 1.5 * 8.0, None)[0]
         assert np.array_equal(pp, ref)
+    # plans that carry a stage spacing (plans_per_stage[stage].current_spacing, nnUNetTrainer.py:594-596): the case is cropped,
+    # resampled (order 3) and normalised on the device before the networks, and the exporter brings it back onto its own grid
+    plans2 = dict(plans, plans_per_stage=[{"current_spacing": [8.0, 1.8, 1.7]}], normalization_schemes={"0": "nonCT"}, use_mask_for_norm={"0": False},
+                  preprocessor_name="PreprocessorFor2D")
+    model2 = str(tmp_path / "model2")
+    P.save_model_folder(model2, seg, flow, plans2, fold=0, seg_sd=sd_s, flow_sd=sd_f)
+    tr, _ = P.load_model_and_checkpoint_files(model2, [0], device=dev)
+    d, sg, props = tr.preprocess_patient([str(inp / "patient001" / "patient001_frame00_0000.nii.gz")])
+    assert d.shape == (1, Z, 50, 49) and d.dtype == np.float32 and abs(float(d.mean())) < 1e-4 and abs(float(d.std()) - 1.0) < 1e-3
+    assert tuple(props["size_after_resampling"]) == (Z, 50, 49) and np.allclose(props["spacing_after_resampling"], (8.0, 1.8, 1.7))
+    P.predict_from_folder(model2, str(inp), str(tmp_path / "out3"), [0], False, 1, 1, None, 0, 2, False)
+    for t in range(T):
+        case = "patient001_frame%02d" % t
+        s3, pr3 = read_nifti(str(tmp_path / "out3" / "patient001" / "Segmentation" / (case + ".nii.gz")))
+        f3 = np.load(str(tmp_path / "out3" / "patient001" / "Flow" / (case + ".npz")))
+        assert s3.shape == (Z, Y, X) and np.allclose(pr3["itk_spacing"], (1.5, 1.5, 8.0)) and f3["flow"].shape == (Y, X, Z, 2)
     # the reference's helper entry points exist with its argument lists
     for name in ("predict_flow", "predict_non_flow", "predict_cases_fast", "predict_cases_fastest", "put_ed_first", "get_ed_es_indices",
                  "load_remove_save", "load_postprocessing"):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel micro-benchmarks on the shapes of the BASELINE workload (B = slices per step).
-Usage: python tools/microbench.py [--batch 16] [--only conv|gn|corr|attn|warp]"""
+Usage: python tools/microbench.py [--batch 16] [--only conv|gn|corr|attn|warp|pre]"""
 import argparse
 import math
 import os
@@ -102,6 +102,43 @@ def main():
         t = timeit(lambda: ops.jacobian_det(flow))
         print("  jacobian B%3d: %8.1f us  %6.0f GB/s" % (B, t * 1e6, B * 65536 * (8 + 8) / t / 1e9))
 
+    if args.only in ("", "pre"):
+        # test-time preprocessing of one ACDC-sized case (BASELINE config 1 volume): wall time per stage, device resident, next to the
+        # CPU oracle (scipy) on the same array; bytes = fp32 volume in + out
+        import time
+        import numpy as np
+        from cineflow import preprocessing as P
+        sys.path.insert(0, ROOT)
+        from oracle import preprocess as OP
+        print("== preprocessing, volume [1, 10, 256, 216] spacing (10, 1.5625, 1.5625) -> (10, 1.25, 1.25)")
+        rng = np.random.default_rng(0)
+        vol = (rng.normal(size=(1, 10, 256, 216)) * 120 + 400).astype(np.float32)
+        vol[:, :, :20] = 0
+        vol[:, :, :, -16:] = 0
+        vd = torch.from_numpy(vol).to(dev)
+        osp, tsp = np.array([10.0, 1.5625, 1.5625]), np.array([10.0, 1.25, 1.25])
+
+        def wall(fn, n=5):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+        t = wall(lambda: P.crop_to_nonzero(vd))
+        c, sg, _ = P.crop_to_nonzero(vd)
+        t0 = time.perf_counter(); OP.crop_to_nonzero(vol.copy()); tc = time.perf_counter() - t0
+        print("  crop_to_nonzero          : %8.1f us   (CPU oracle %8.1f us)" % (t * 1e6, tc * 1e6))
+        t = wall(lambda: P.resample_patient(c, None, osp, tsp, 3, 1, order_z_data=0, order_z_seg=0))
+        r = P.resample_patient(c, None, osp, tsp, 3, 1, order_z_data=0, order_z_seg=0)[0]
+        cn = c.cpu().numpy()
+        t0 = time.perf_counter(); OP.resample_patient(cn.copy(), None, osp, tsp, 3, 1, order_z_data=0, order_z_seg=0); tc = time.perf_counter() - t0
+        print("  resample order 3 %s -> %s: %8.1f us  %6.1f GB/s (CPU oracle %8.1f us)" % (tuple(c.shape[1:]), tuple(r.shape[1:]), t * 1e6,
+                                                                                       4.0 * (c.numel() + r.numel()) / t / 1e9, tc * 1e6))
+        pre = P.PreprocessorFor2D({0: "nonCT"}, {0: False}, [0, 1, 2])
+        t = wall(lambda: pre.resample_and_normalize(c.clone(), tsp, {"original_spacing": osp}, sg.clone()))
+        print("  resample_and_normalize   : %8.1f us" % (t * 1e6))
 
 if __name__ == "__main__":
     main()
