@@ -4,7 +4,7 @@
 //     components come from the connected-component sweeps of postprocess.hip), bounding box;
 //   * cubic-spline resampling (preprocessing.py:111-200 through skimage.transform.resize(order=3, mode='edge') =
 //     scipy.ndimage.zoom(order=3, mode='nearest', grid_mode=True)): one separable pass per axis -- edge-pad 12 samples, the recursive
-//     B-spline prefilter of scipy.s ni_splines.c (pole sqrt(3)-2, mirror initialisation) unrolled into its impulse response, 4-tap evaluation at
+//     B-spline prefilter of scipy's ni_splines.c (pole sqrt(3)-2, mirror initialisation) unrolled into its impulse response, 4-tap evaluation at
 //     src = (dst + 0.5) n/m - 0.5.  All in fp64 like the reference, which resamples `data.astype(float)`;
 //   * per-slab clipping to the input range (resize's clip=True) and intensity normalisation (preprocessing.py:274-320).
 // Volumes are a few MB: launch-latency scale work; every kernel is one thread per voxel (no serial per-line recursion) and reductions
