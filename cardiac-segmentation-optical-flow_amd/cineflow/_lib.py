@@ -79,6 +79,14 @@ SIGNATURES = {
     "cf_nan_to_zero": [P, L, P],
     "cf_assign_where_ge": [P, P, L, F, F, P],
     "cf_seg_outside_mask": [P, P, I, L, F, P],
+    "cf_confusion_counts": [P, P, L, P, P],
+    "cf_label_confusion": [P, P, L, I, P, P],
+    "cf_surface_border": [P, I, I, I, I, P, P, P],
+    "cf_surface_min_dist": [P, I, P, I, DBL, DBL, DBL, P, P],
+    "cf_max_sum_nonneg": [P, L, P, P],
+    "cf_region_stats": [P, P, L, I, P, P],
+    "cf_spatial_gradient3d": [P, P, L, I, I, I, P],
+    "cf_slab_abs_sum": [P, I, I, I, L, P, P],
     "cf_profile_enable": [I],
     "cf_profile_reset": [],
     "cf_profile_read": [I, P, P, P],

@@ -248,6 +248,28 @@ int cf_assign_where_ge(float* dst, const float* src, long n, float thr, float va
 /* cropping.py:128-135: seg [C][V] gets `label` where seg == 0 and mask [V] == 0 (a zero-filled seg yields the created one) */
 int cf_seg_outside_mask(float* seg, const uint8_t* mask, int C, long V, float label, void* stream);
 
+/* ---------------------------------------------------------------- downstream metrics (consumers of the output layout)
+ * ConfusionMatrix.compute, nnunet/evaluation/metrics.py:65-82: counts3 (device u64 [3]) = {TP, FP, FN} of test != 0 vs
+ * reference != 0 over n voxels (TN = n - TP - FP - FN). */
+int cf_confusion_counts(const uint8_t* test, const uint8_t* reference, long n, unsigned long long* counts3, void* stream);
+/* all classes of nnunet/compute_metrics.py:96-106 in one pass: hist (device u64 [K*K + 1]), hist[t*K + r] = #voxels with test label t
+ * and reference label r; hist[K*K] counts voxels with a label >= K.  K <= 16. */
+int cf_label_confusion(const uint8_t* test, const uint8_t* reference, long n, int K, unsigned long long* hist, void* stream);
+/* medpy.metric.binary.__surface_distances (behind metrics.py:323-392): border voxels of mask [D,H,W] (mask ^ binary_erosion(mask,
+ * generate_binary_structure(ndim, 1))) compacted as int32 (z, y, x) triples into coords (capacity 3*D*H*W); *count (device int32)
+ * receives their number.  Then dist[i] = min_j ||spacing * (a[i] - b[j])|| in fp64 (= distance_transform_edt(~border_b, sampling)
+ * read at border_a), and {max, sum} of a non-negative fp64 array -> out2. */
+int cf_surface_border(const uint8_t* mask, int D, int H, int W, int ndim, int* coords, int* count, void* stream);
+int cf_surface_min_dist(const int* a, int na, const int* b, int nb, double sz, double sy, double sx, double* dist, void* stream);
+int cf_max_sum_nonneg(const double* x, long n, double* out2, void* stream);
+/* nnunet/compute_jacobian.py:160-186: per label k < K (<= 16) of `labels`, stats (device fp64 [3*K]) = {sum x, count, #(x < 0)} */
+int cf_region_stats(const double* x, const uint8_t* labels, long n, int K, double* stats, void* stream);
+/* kornia.filters.spatial_gradient3d(mode='diff', order=1) of compute_jacobian.py:146: x [N][D][H][W] -> out [N][3][D][H][W]
+ * (component 0 along W, 1 along H, 2 along D), replicate-padded central differences times 0.5; and the sums of |x| per slab
+ * (c, s) of x [C][A][S][B] -> sums fp64 [C*S] behind the per-frame means of :147-159. */
+int cf_spatial_gradient3d(const float* x, float* out, long N, int D, int H, int W, void* stream);
+int cf_slab_abs_sum(const float* x, int C, int A, int S, long B, double* sums, void* stream);
+
 /* ---------------------------------------------------------------- measurement hooks (bench.py only; no reference analogue)
  * cf_profile_enable(n): pre-create n event pairs and time every conv / CorrVolume launch with a (start, stop) pair that
  * brackets exactly that kernel on its own stream (hipExtLaunchKernelGGL); 0 disables.  Kernel ids:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel micro-benchmarks on the shapes of the BASELINE workload (B = slices per step).
-Usage: python tools/microbench.py [--batch 16] [--only conv|gn|corr|attn|warp|pre]"""
+Usage: python tools/microbench.py [--batch 16] [--only conv|gn|corr|attn|warp|pre|metrics]"""
 import argparse
 import math
 import os
@@ -139,6 +139,44 @@ def main():
         pre = P.PreprocessorFor2D({0: "nonCT"}, {0: False}, [0, 1, 2])
         t = wall(lambda: pre.resample_and_normalize(c.clone(), tsp, {"original_spacing": osp}, sg.clone()))
         print("  resample_and_normalize   : %8.1f us" % (t * 1e6))
+    if args.only in ("", "metrics"):
+        # the per-case work of compute_metrics.py (3 classes x Dice / HD / ASSD) on one ACDC-sized label volume, device vs CPU oracle
+        import time
+        import numpy as np
+        from cineflow import metrics as M
+        sys.path.insert(0, ROOT)
+        from oracle import metrics as OM
+        print("== metrics, label volumes [10, 256, 216], spacing (10, 1.5625, 1.5625)")
+        zz, yy, xx = np.meshgrid(np.arange(10), np.arange(256), np.arange(216), indexing="ij")
+
+        def labels(shift):
+            lab = np.zeros((10, 256, 216), np.uint8)
+            for c, r in ((1, 60), (2, 42), (3, 30)):
+                lab[(yy - 128 - shift) ** 2 + (xx - 108 + shift) ** 2 <= (r - 2 * np.abs(zz - 5)) ** 2] = c
+            return lab
+        a, b, sp = labels(0), labels(3), (10.0, 1.5625, 1.5625)
+        ad, bd = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+
+        def case(mod, x, y):
+            out = []
+            for c in (1, 2, 3):
+                out += [mod.dice(x == c, y == c), mod.hausdorff_distance(x == c, y == c, voxel_spacing=sp),
+                        mod.avg_surface_distance_symmetric(x == c, y == c, voxel_spacing=sp)]
+            return out
+        case(M, ad, bd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r = case(M, ad, bd)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / 5
+        t0 = time.perf_counter(); ro = case(OM, a, b); tc = time.perf_counter() - t0
+        print("  Dice + HD + ASSD x 3 classes: %8.1f us   (CPU oracle %8.1f us)   max|diff| %.2e" % (t * 1e6, tc * 1e6, float(np.abs(np.array(r) - np.array(ro)).max())))
+        t0 = time.perf_counter()
+        for _ in range(5):
+            M.label_confusion(ad, bd, 4)
+        torch.cuda.synchronize()
+        print("  label_confusion (all classes, one pass): %8.1f us" % ((time.perf_counter() - t0) / 5 * 1e6))
 
 if __name__ == "__main__":
     main()
