@@ -93,6 +93,9 @@ class Conv2d(Module):
 
     def forward(self, x, x2=None, act=None, res=None, out=None, out_coff=0, stats_groups=None):
         """stats_groups=G: returns (out, ws) with the GroupNorm statistics of `out` when the f16 kernel can fuse them, else (out, None)."""
+        if (x2 is None and act is None and res is None and out is None and ops.CONV_MODE == "f16s"
+                and ops.small_cin_supported(self.cin, self.ks[0], self.ks[1], self.stride, self.pad, stats_groups)):
+            return ops.conv2d_small_cin(x, self._p["weight"], self._p.get("bias"), stats_groups)      # the stems: direct fp32, HBM-bound
         if self._f16s and ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, x2, self.ks[0]):
             return ops.conv2d_f16s(x, self._wpk, self._ws, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad,
                                    x2=x2, act=act, res=res, out=out, out_coff=out_coff, stats_groups=stats_groups)

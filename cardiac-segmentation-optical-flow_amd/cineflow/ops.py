@@ -4,6 +4,8 @@ PyTorch is used for device memory (torch.empty on the caching allocator) and the
 number is produced by a hand-written HIP kernel in libcineflow_hip.so.  Inputs must be CUDA(=HIP) tensors; nothing
 here runs on the CPU and nothing falls back to torch operators.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -231,6 +233,33 @@ def conv2d_f16s(x1, wpk, wscale, bias, cout, kh, kw, stride=1, pad=(0, 0), x2=No
     check(lib().cf_conv2d_f16s(_f32(x1), C1, _opt(x2), C2, wpk.data_ptr(), _opt(bias), _opt(res), _f32(out), out.shape[1], out_coff, B, H, W,
                                cout, kh, kw, stride, pad[0], pad[1], ACT[act], float(alpha) * (2.0 ** -wscale),
                                None if ws is None else ws.data_ptr(), -stats_groups if stats_groups else 0, _stream()), "cf_conv2d_f16s")
+    return (out, ws) if stats_groups else out
+
+
+DIRECT_STEM = os.environ.get("CF_CONV_DIRECT", "1") != "0"      # 0: the stems go through the MFMA kernels like every other layer (A/B knob)
+
+
+def small_cin_supported(cin, kh, kw, stride, pad, stats_groups=None):
+    """layers routed to cf_conv2d_small_cin: 1 or 2 input channels (3x3 pad 1 or 1x1) and 6 input channels 1x1, stride 1, <= 64
+    statistics groups.  Measured at 256x256 (tools/microbench.py --only stem): 1 -> 32 B120 209 us vs 641 us on the MFMA kernel,
+    1 -> 64 106 vs 238, 6 -> 64 1x1 120 vs 194; the 6 -> 64 3x3 layer is FMA-bound in the direct kernel (304 vs 257 us) and stays
+    on the MFMA kernel."""
+    if not DIRECT_STEM or stride != 1 or (stats_groups and stats_groups > 64):
+        return False
+    k3, k1 = (kh, kw, tuple(pad)) == (3, 3, (1, 1)), (kh, kw, tuple(pad)) == (1, 1, (0, 0))
+    return (cin in (1, 2) and (k3 or k1)) or (cin == 6 and k1)
+
+
+def conv2d_small_cin(x, weight, bias, stats_groups=None):
+    """Stem convolution as a direct fp32 kernel: x [B,Cin,H,W], weight [Cout,Cin,K,K] (checkpoint layout).  With stats_groups=G the
+    call returns (out, ws) like conv2d_f16s."""
+    B, Cin, H, W = x.shape
+    cout, cin_w, K, K2 = weight.shape
+    assert cin_w == Cin and K == K2
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
+    check(lib().cf_conv2d_small_cin(_f32(x), _f32(weight), _opt(bias), _f32(out), B, Cin, H, W, cout, K, None if ws is None else ws.data_ptr(),
+                                    stats_groups or 0, _stream()), "cf_conv2d_small_cin")
     return (out, ws) if stats_groups else out
 
 

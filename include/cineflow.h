@@ -218,6 +218,13 @@ int cf_cc_remove(uint8_t* image, const int* labels, const int* counts, long n, i
 int cf_resize3d(const float* src, float* dst, int N, int X, int Y, int Z, int X2, int Y2, int Z2, int linear_x, int linear_y,
                 int linear_z, void* stream);
 
+/* Stem convolutions (nn.Conv2d with 1, 2 or 6 input channels, 3x3 pad 1 or 1x1, stride 1, e.g. Generic_UNet's first conv,
+ * nnunet/network_architecture/generic_UNet.py:70-86, and the encoders' first DoubleConv, nnunet/lib/utils.py:1175-1210) as a direct
+ * fp32 kernel: weight fp32 [Cout][Cin][K][K] (the checkpoint layout), out dense [B][Cout][H][W].  gn_ws (may be NULL): device fp64
+ * [B][gn_groups][2] = {sum, sum of squares} of the output per (sample, group), zeroed here; gn_groups <= 64 divides Cout. */
+int cf_conv2d_small_cin(const float* x, const float* weight, const float* bias, float* out, int B, int Cin, int H, int W, int Cout, int K,
+                        double* gn_ws, int gn_groups, void* stream);
+
 /* ---------------------------------------------------------------- test-time preprocessing (the step before the path)
  * create_nonzero_mask, nnunet/preprocessing/cropping.py:25-32: mask[v] = any_c data[c][v] != 0 (uint8 [V]). */
 int cf_nonzero_mask(const float* data, int C, long V, uint8_t* mask, void* stream);

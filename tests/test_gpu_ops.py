@@ -354,6 +354,37 @@ def test_conv_f16s_many_tiles(dev, B, C1, C2, H, W, Cout, groups):
     assert float(big[:, :8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,K,groups", [
+    (3, 1, 64, 64, 32, 3, 32),        # Generic_UNet stem, InstanceNorm statistics (one group per channel)
+    (2, 1, 256, 256, 64, 3, 8),       # flow encoder stem, GroupNorm(8)
+    (2, 6, 70, 100, 64, 3, 8),        # ragged: 70 rows (not a multiple of the 8-row blocks), 100 columns (not a multiple of 64)
+    (2, 6, 64, 64, 64, 1, 8),         # 1x1 downsample branch of the stem
+    (1, 2, 33, 17, 16, 3, None),      # two channels, no statistics, image smaller than a block
+    (2, 1, 40, 72, 24, 1, 4),
+])
+def test_conv_small_cin(dev, B, Cin, H, W, Cout, K, groups):
+    """cf_conv2d_small_cin (direct fp32 stem convolution) and its fused statistics against torch; exact fp32 FMA chain, so the
+    tolerance is fp32 summation order on <= 54 terms of O(1) products (5e-6 on outputs up to ~5)."""
+    from cineflow import ops
+    x = randn(B, Cin, H, W, seed=80)
+    w = randn(Cout, Cin, K, K, seed=81) / math.sqrt(Cin * K * K)
+    b = randn(Cout, seed=82)
+    y = F.conv2d(x, w, b, padding=K // 2)
+    assert ops.small_cin_supported(Cin, K, K, 1, (K // 2, K // 2), groups) == (not (Cin == 6 and K == 3))
+    r = ops.conv2d_small_cin(x.to(dev), w.to(dev), b.to(dev), groups)
+    out, stats = r if groups else (r, None)
+    check(out, y, 5e-6, "direct conv")
+    if groups:
+        yo = out.cpu().double()
+        want = torch.stack([yo.view(B, groups, -1).sum(-1), (yo ** 2).view(B, groups, -1).sum(-1)], -1)
+        scale = yo.abs().view(B, groups, -1).sum(-1)[..., None] + 1.0
+        assert float(((stats.cpu().view(B, groups, 2) - want).abs() / scale).max()) <= 2e-6
+    check(ops.conv2d_small_cin(x.to(dev), w.to(dev), None, None), F.conv2d(x, w, None, padding=K // 2), 5e-6, "direct conv, no bias")
+    assert not ops.small_cin_supported(3, 3, 3, 1, (1, 1)) and not ops.small_cin_supported(1, 3, 3, 2, (1, 1))
+    with pytest.raises(RuntimeError):
+        ops.conv2d_small_cin(randn(1, 3, 8, 8, seed=1).to(dev), randn(4, 3, 3, 3, seed=2).to(dev), None, None)
+
+
 def test_conv_f16s_dynamic_range(dev):
     """tiny and large operands: the weight pre-scaling keeps the lo halves normal; activations lose <= 2^-25 absolute."""
     from cineflow import ops

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel micro-benchmarks on the shapes of the BASELINE workload (B = slices per step).
-Usage: python tools/microbench.py [--batch 16] [--only conv|gn|corr|attn|warp|pre|metrics]"""
+Usage: python tools/microbench.py [--batch 16] [--only conv|gn|corr|attn|warp|pre|metrics|stem]"""
 import argparse
 import math
 import os
@@ -139,6 +139,19 @@ def main():
         pre = P.PreprocessorFor2D({0: "nonCT"}, {0: False}, [0, 1, 2])
         t = wall(lambda: pre.resample_and_normalize(c.clone(), tsp, {"original_spacing": osp}, sg.clone()))
         print("  resample_and_normalize   : %8.1f us" % (t * 1e6))
+    if args.only in ("", "stem"):
+        print("== stem convolutions (direct fp32 kernel vs the f16-split MFMA kernel), bytes = 4 B H W (Cin + Cout), fused statistics")
+        for (Bs, Cin, Cout, K, groups) in [(120, 1, 32, 3, 32), (32, 1, 64, 3, 8), (32, 6, 64, 3, 8), (32, 6, 64, 1, 8)]:
+            x = torch.randn(Bs, Cin, 256, 256, generator=g).to(dev)
+            w = (torch.randn(Cout, Cin, K, K, generator=g) / math.sqrt(Cin * K * K)).to(dev)
+            b = torch.randn(Cout, generator=g).to(dev)
+            wpk, ws_ = ops.pack_conv_weight_f16s(w)
+            t1 = timeit(lambda: ops.conv2d_small_cin(x, w, b, groups))
+            t2 = timeit(lambda: ops.conv2d_f16s(x, wpk, ws_, b, Cout, K, K, 1, (K // 2, K // 2), stats_groups=groups))
+            by = 4.0 * Bs * 65536 * (Cin + Cout)
+            print("  B%3d C%d -> %2d k%d: direct %8.1f us %6.0f GB/s | f16s %8.1f us %6.0f GB/s" % (Bs, Cin, Cout, K, t1 * 1e6, by / t1 / 1e9, t2 * 1e6,
+                                                                                               by / t2 / 1e9))
+
     if args.only in ("", "metrics"):
         # the per-case work of compute_metrics.py (3 classes x Dice / HD / ASSD) on one ACDC-sized label volume, device vs CPU oracle
         import time
