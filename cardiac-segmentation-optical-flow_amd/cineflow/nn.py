@@ -8,6 +8,8 @@ channel-first ([B,C,N]) so the reference's permute/contiguous round trips never 
 """
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -139,8 +141,15 @@ class GroupNorm(Module):
         self._param("weight", (channels,))
         self._param("bias", (channels,))
 
-    def forward(self, x, act=None, res=None, res_mode=None, inplace=True, ws=None):
-        """ws: statistics already accumulated by the producing convolution's epilogue -> apply pass only."""
+    def forward(self, x, act=None, res=None, res_mode=None, inplace=True, ws=None, res_norm=None):
+        """ws: statistics already accumulated by the producing convolution's epilogue -> apply pass only.
+        res_norm=(raw residual's statistics, its GroupNorm module): that norm is applied to `res` inside this pass."""
+        if res_norm is not None:
+            ws_r, norm_r = res_norm
+            if ws is not None and ws_r is not None and norm_r.groups == self.groups and norm_r.eps == self.eps:
+                return ops.group_norm_apply(x, self._p["weight"], self._p["bias"], self.groups, ws, self.eps, act=act, res=res, res_mode=res_mode,
+                                            out=x if inplace else None, res_norm=(ws_r, norm_r._p["weight"], norm_r._p["bias"]))
+            res = norm_r(res, ws=ws_r)          # the branch's own pass (statistics not fused, or different group counts)
         if ws is not None:
             return ops.group_norm_apply(x, self._p["weight"], self._p["bias"], self.groups, ws, self.eps, act=act, res=res,
                                         res_mode=res_mode, out=x if inplace else None)
@@ -148,11 +157,11 @@ class GroupNorm(Module):
                               out=x if inplace else None)
 
 
-def conv_norm(conv, norm, x, x2=None, act=None, res=None, res_mode=None):
+def conv_norm(conv, norm, x, x2=None, act=None, res=None, res_mode=None, res_norm=None):
     """norm(conv(x)) with the GroupNorm statistics accumulated in the convolution's epilogue when possible."""
     kw = {} if x2 is None else {"x2": x2}
     y, ws = conv(x, stats_groups=norm.groups, **kw)
-    return norm(y, act=act, res=res, res_mode=res_mode, ws=ws)
+    return norm(y, act=act, res=res, res_mode=res_mode, ws=ws, res_norm=res_norm)
 
 
 class LayerNormCF(Module):
@@ -279,6 +288,9 @@ class InstanceNorm3d(Module):
         return y.view(B, C, D, H, W)
 
 # --------------------------------------------------------------------------------------------- lib/utils.py blocks
+FUSE_RES_NORM = os.environ.get("CF_FUSE_RES_NORM", "1") != "0"     # 0: the downsample branch's GroupNorm runs as its own pass (A/B knob)
+
+
 class DoubleConv(Module):
     """nnunet/lib/utils.py:1182-1215: GELU(GN(conv)) twice, residual (optionally 1x1 conv + GN) added after the
     second GELU.  `x2` is the second half of a channel concatenation (never materialised)."""
@@ -299,7 +311,12 @@ class DoubleConv(Module):
         if not self.residual:
             return conv_norm(self.conv2, self.norm2, t, act="gelu")
         if self.has_ds:
-            r = conv_norm(self.downsample[0], self.downsample[1], x, x2=x2)
+            # the branch's GroupNorm rides in the final apply pass: GELU(GN2(conv2(t))) + GN_ds(conv1x1(x)) in one kernel
+            kw = {} if x2 is None else {"x2": x2}
+            r, ws_r = self.downsample[0](x, stats_groups=self.downsample[1].groups, **kw)
+            if FUSE_RES_NORM:
+                return conv_norm(self.conv2, self.norm2, t, act="gelu", res=r, res_mode="after_act", res_norm=(ws_r, self.downsample[1]))
+            r = self.downsample[1](r, ws=ws_r)
         else:
             assert x2 is None
             r = x

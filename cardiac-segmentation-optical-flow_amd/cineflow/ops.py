@@ -329,13 +329,22 @@ def group_norm(x, gamma, beta, groups, eps=1e-5, act=None, res=None, res_mode=No
     return out
 
 
-def group_norm_apply(x, gamma, beta, groups, ws, eps=1e-5, act=None, res=None, res_mode=None, out=None):
-    """Apply pass only; `ws` from conv2d_f16s(..., stats_groups=groups)."""
+def group_norm_apply(x, gamma, beta, groups, ws, eps=1e-5, act=None, res=None, res_mode=None, out=None, res_norm=None):
+    """Apply pass only; `ws` from conv2d_f16s(..., stats_groups=groups).  res_norm=(ws_r, gamma_r, beta_r): `res` is a raw
+    convolution output whose own GroupNorm (same groups / eps) is applied on the fly while it is added."""
     B, C = x.shape[0], x.shape[1]
     HW = x.numel() // (B * C)
     if out is None:
         out = torch.empty_like(x)
     assert ws.dtype == torch.float64 and ws.numel() >= 2 * B * groups
+    if res_norm is not None:
+        ws_r, gamma_r, beta_r = res_norm
+        assert res is not None and res_mode in ("before_act", "after_act") and res.shape == x.shape
+        assert ws_r.dtype == torch.float64 and ws_r.numel() >= 2 * B * groups
+        check(lib().cf_group_norm_apply_res_norm(_f32(x), _opt(gamma), _opt(beta), _f32(res), _f32(out), B, C, HW, groups, float(eps), ACT[act],
+                                                 RES[res_mode], ws.data_ptr(), ws_r.data_ptr(), _opt(gamma_r), _opt(beta_r), _stream()),
+              "cf_group_norm_apply_res_norm")
+        return out
     check(lib().cf_group_norm_apply(_f32(x), _opt(gamma), _opt(beta), _opt(res), _f32(out), B, C, HW, groups, float(eps), ACT[act],
                                     RES[res_mode if res is not None else None], ws.data_ptr(), _stream()), "cf_group_norm_apply")
     return out

@@ -58,13 +58,20 @@ __global__ void __launch_bounds__(256) gn_stats_block_kernel(const float* __rest
     }
 }
 
+// optional normalisation of the residual operand (all NULL: the residual is added as it is)
+struct ResNorm {
+    const double* ws;
+    const float* gamma;
+    const float* beta;
+};
+
 // Apply pass.  A block works inside ONE (sample, channel) plane, so mean / rstd / gamma / beta are block-uniform scalars
 // (computed once per block from the fp64 sums) and the element loop is a pure float4 stream: y = act((x-mean)*rstd*g+b [+res]) [+res].
 template <bool VEC>
 __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ res,
                                                        float* __restrict__ out, const double* __restrict__ ws, int C, int HW,
-                                                       int groups, float eps, int act, int res_mode, int segs) {
+                                                       int groups, float eps, int act, int res_mode, int segs, ResNorm rn) {
     const long plane = blockIdx.x / segs;  // b*C + c
     const int seg = blockIdx.x % segs;
     const int c = (int)(plane % C);
@@ -77,6 +84,18 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float mean = (float)mean_d;
     const float g = gamma ? gamma[c] : 1.f, bb = beta ? beta[c] : 0.f;
+    // residual that is itself a raw convolution output awaiting ITS GroupNorm (the 1x1 downsample branch of DoubleConv): r is
+    // normalised here on the fly, r' = (r - rm) * ra + rb, instead of in a pass of its own (rm = 0, ra = 1, rb = 0: r' = r exactly)
+    float rm = 0.f, ra = 1.f, rb = 0.f;
+    if (rn.ws) {
+        const double rmean = rn.ws[2 * slab] * invL;
+        double rvar = rn.ws[2 * slab + 1] * invL - rmean * rmean;
+        if (rvar < 0.0) rvar = 0.0;
+        const float rrstd = (float)(1.0 / sqrt(rvar + (double)eps)), rg = rn.gamma ? rn.gamma[c] : 1.f;
+        rm = (float)rmean;
+        ra = rrstd * rg;
+        rb = rn.beta ? rn.beta[c] : 0.f;
+    }
     const long base = plane * HW;
     if (VEC) {
         const int n4 = HW >> 2;
@@ -88,7 +107,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
             if (res_mode != CF_RES_NONE) r = r4[i];
             float t[4] = {v.x, v.y, v.z, v.w};
-            const float rr[4] = {r.x, r.y, r.z, r.w};
+            const float rr[4] = {(r.x - rm) * ra + rb, (r.y - rm) * ra + rb, (r.z - rm) * ra + rb, (r.w - rm) * ra + rb};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float y = (t[k] - mean) * rstd * g + bb;
@@ -102,9 +121,10 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
     } else {
         for (int i = seg * 256 + threadIdx.x; i < HW; i += segs * 256) {
             float y = (x[base + i] - mean) * rstd * g + bb;
-            if (res_mode == CF_RES_BEFORE_ACT) y += res[base + i];
+            const float r = res_mode != CF_RES_NONE ? (res[base + i] - rm) * ra + rb : 0.f;
+            if (res_mode == CF_RES_BEFORE_ACT) y += r;
             y = act_apply(y, act);
-            if (res_mode == CF_RES_AFTER_ACT) y += res[base + i];
+            if (res_mode == CF_RES_AFTER_ACT) y += r;
             out[base + i] = y;
         }
     }
@@ -118,8 +138,9 @@ template <bool VEC>
 __global__ void __launch_bounds__(256) gn_apply_small_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, const float* __restrict__ res,
                                                              float* __restrict__ out, const double* __restrict__ ws, int C, int HW,
-                                                             int groups, float eps, int act, int res_mode, long planes, int ppb) {
+                                                             int groups, float eps, int act, int res_mode, long planes, int ppb, ResNorm rn) {
     __shared__ float coef[GN_SMALL_MAXP][4];
+    __shared__ float rcoef[GN_SMALL_MAXP][4];
     const long p0 = (long)blockIdx.x * ppb;
     const int np = (int)(planes - p0 < ppb ? planes - p0 : ppb);
     const int cpg = C / groups;
@@ -135,6 +156,18 @@ __global__ void __launch_bounds__(256) gn_apply_small_kernel(const float* __rest
         coef[t][1] = (float)(1.0 / sqrt(var + (double)eps));
         coef[t][2] = gamma ? gamma[c] : 1.f;
         coef[t][3] = beta ? beta[c] : 0.f;
+        float rm = 0.f, ra = 1.f, rb = 0.f;
+        if (rn.ws) {
+            const double rmean = rn.ws[2 * slab] * invL;
+            double rvar = rn.ws[2 * slab + 1] * invL - rmean * rmean;
+            if (rvar < 0.0) rvar = 0.0;
+            rm = (float)rmean;
+            ra = (float)(1.0 / sqrt(rvar + (double)eps)) * (rn.gamma ? rn.gamma[c] : 1.f);
+            rb = rn.beta ? rn.beta[c] : 0.f;
+        }
+        rcoef[t][0] = rm;
+        rcoef[t][1] = ra;
+        rcoef[t][2] = rb;
     }
     __syncthreads();
     const long base = p0 * HW;
@@ -149,11 +182,12 @@ __global__ void __launch_bounds__(256) gn_apply_small_kernel(const float* __rest
             if ((pl + 1) * HW <= 4 * i) ++pl;                       // exact for any HW: correct the float estimate
             if (pl * HW > 4 * i) --pl;
             const float mean = coef[pl][0], rstd = coef[pl][1], g = coef[pl][2], bb = coef[pl][3];
+            const float rm = rcoef[pl][0], ra = rcoef[pl][1], rb = rcoef[pl][2];
             const float4 v = x4[i];
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
             if (res_mode != CF_RES_NONE) r = r4[i];
             float t[4] = {v.x, v.y, v.z, v.w};
-            const float rr[4] = {r.x, r.y, r.z, r.w};
+            const float rr[4] = {(r.x - rm) * ra + rb, (r.y - rm) * ra + rb, (r.z - rm) * ra + rb, (r.w - rm) * ra + rb};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float y = (t[k] - mean) * rstd * g + bb;
@@ -171,9 +205,10 @@ __global__ void __launch_bounds__(256) gn_apply_small_kernel(const float* __rest
             if ((pl + 1) * HW <= i) ++pl;
             if (pl * HW > i) --pl;
             float y = (x[base + i] - coef[pl][0]) * coef[pl][1] * coef[pl][2] + coef[pl][3];
-            if (res_mode == CF_RES_BEFORE_ACT) y += res[base + i];
+            const float r = res_mode != CF_RES_NONE ? (res[base + i] - rcoef[pl][0]) * rcoef[pl][1] + rcoef[pl][2] : 0.f;
+            if (res_mode == CF_RES_BEFORE_ACT) y += r;
             y = act_apply(y, act);
-            if (res_mode == CF_RES_AFTER_ACT) y += res[base + i];
+            if (res_mode == CF_RES_AFTER_ACT) y += r;
             out[base + i] = y;
         }
     }
@@ -263,7 +298,7 @@ int launch_gn_stats(const float* x, double* ws, int B, int C, int HW, int groups
 using namespace cf;
 
 static int gn_apply_launch(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C, int HW,
-                           int groups, float eps, int act, int res_mode, const double* ws, hipStream_t s);
+                           int groups, float eps, int act, int res_mode, const double* ws, hipStream_t s, ResNorm rn = ResNorm{nullptr, nullptr, nullptr});
 
 extern "C" int cf_group_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,
                              int HW, int groups, float eps, int act, int res_mode, double* ws, void* stream) {
@@ -288,8 +323,20 @@ extern "C" int cf_group_norm_apply(const float* x, const float* gamma, const flo
     return gn_apply_launch(x, gamma, beta, res, out, B, C, HW, groups, eps, act, res_mode, ws, as_stream(stream));
 }
 
+// cf_group_norm_apply with a residual that still awaits its own GroupNorm (same group count and eps): res_ws holds the residual's
+// (sum, sum of squares) pairs, res_gamma / res_beta its affine parameters.
+extern "C" int cf_group_norm_apply_res_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,
+                                            int HW, int groups, float eps, int act, int res_mode, const double* ws, const double* res_ws,
+                                            const float* res_gamma, const float* res_beta, void* stream) {
+    CF_REQUIRE(x && out && ws && res && res_ws, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0, "bad shape B=%d C=%d HW=%d groups=%d", B, C, HW, groups);
+    CF_REQUIRE(res_mode == CF_RES_BEFORE_ACT || res_mode == CF_RES_AFTER_ACT, "a normalised residual needs a residual mode, got %d", res_mode);
+    CF_REQUIRE(act >= CF_ACT_NONE && act <= CF_ACT_SIGMOID, "bad activation %d", act);
+    return gn_apply_launch(x, gamma, beta, res, out, B, C, HW, groups, eps, act, res_mode, ws, as_stream(stream), ResNorm{res_ws, res_gamma, res_beta});
+}
+
 static int gn_apply_launch(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C, int HW,
-                           int groups, float eps, int act, int res_mode, const double* ws, hipStream_t s) {
+                           int groups, float eps, int act, int res_mode, const double* ws, hipStream_t s, ResNorm rn) {
     if (HW < 2048) {
         const long planes_s = (long)B * C;
         int ppb = 4096 / HW;
@@ -300,10 +347,10 @@ static int gn_apply_launch(const float* x, const float* gamma, const float* beta
         const bool vec_s = (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(res)) & 15) == 0;
         if (vec_s)
             hipLaunchKernelGGL((gn_apply_small_kernel<true>), dim3((unsigned)nblk), dim3(256), 0, s, x, gamma, beta, res, out, ws, C, HW, groups, eps,
-                               act, res_mode, planes_s, ppb);
+                               act, res_mode, planes_s, ppb, rn);
         else
             hipLaunchKernelGGL((gn_apply_small_kernel<false>), dim3((unsigned)nblk), dim3(256), 0, s, x, gamma, beta, res, out, ws, C, HW, groups, eps,
-                               act, res_mode, planes_s, ppb);
+                               act, res_mode, planes_s, ppb, rn);
         CF_CHECK_LAUNCH();
         return CF_OK;
     }
@@ -315,10 +362,10 @@ static int gn_apply_launch(const float* x, const float* gamma, const float* beta
     CF_REQUIRE(planes * asegs < (1L << 31), "grid too large");
     if (vec)
         hipLaunchKernelGGL((gn_apply_kernel<true>), dim3((unsigned)(planes * asegs)), dim3(256), 0, s, x, gamma, beta, res, out, ws, C, HW, groups,
-                           eps, act, res_mode, asegs);
+                           eps, act, res_mode, asegs, rn);
     else
         hipLaunchKernelGGL((gn_apply_kernel<false>), dim3((unsigned)(planes * asegs)), dim3(256), 0, s, x, gamma, beta, res, out, ws, C, HW, groups,
-                           eps, act, res_mode, asegs);
+                           eps, act, res_mode, asegs, rn);
     CF_CHECK_LAUNCH();
     return CF_OK;
 }

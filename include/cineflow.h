@@ -143,6 +143,12 @@ int cf_group_norm(const float* x, const float* gamma, const float* beta, const f
 /* The apply pass of cf_group_norm alone; `ws` holds the statistics (from cf_conv2d_f16s' fused epilogue). */
 int cf_group_norm_apply(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,
                         int HW, int groups, float eps, int act, int res_mode, const double* ws, void* stream);
+/* The same apply pass when the residual is a raw convolution output that still awaits ITS OWN GroupNorm (the 1x1 conv + GroupNorm
+ * `downsample` branch of DoubleConv, nnunet/lib/utils.py:1192-1195, :1208-1213): res is normalised on the fly with res_ws (its
+ * {sum, sum of squares} pairs, same groups and eps) and res_gamma / res_beta, saving that branch's own apply pass. */
+int cf_group_norm_apply_res_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,
+                                 int HW, int groups, float eps, int act, int res_mode, const double* ws, const double* res_ws,
+                                 const float* res_gamma, const float* res_beta, void* stream);
 
 /* nn.LayerNorm(C) over the channel axis of channel-first tokens x [B,C,N] (lib/vit_transformer.py:1257,1261,1265);
  * the residual add is done by the preceding conv epilogue. */

@@ -354,6 +354,31 @@ def test_conv_f16s_many_tiles(dev, B, C1, C2, H, W, Cout, groups):
     assert float(big[:, :8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 64, 64), (3, 32, 16, 16), (2, 16, 9, 7)])
+@pytest.mark.parametrize("mode", ["after_act", "before_act"])
+def test_group_norm_apply_res_norm(dev, B, C, H, W, mode):
+    """apply pass whose residual is normalised on the fly (DoubleConv's 1x1 conv + GroupNorm branch) against torch and against
+    the two-pass form; large and small plane kernels, vector and scalar paths"""
+    from cineflow import ops
+    G = 8
+    x, r = randn(B, C, H, W, seed=90) * 2 + 0.3, randn(B, C, H, W, seed=91) * 3 - 1.0
+    g1, b1, g2, b2 = randn(C, seed=92), randn(C, seed=93), randn(C, seed=94), randn(C, seed=95)
+    rn = F.group_norm(r, G, g2, b2, eps=1e-5)
+    y = F.group_norm(x, G, g1, b1, eps=1e-5)
+    want = F.gelu(y + rn) if mode == "before_act" else F.gelu(y) + rn
+
+    def stats(t):
+        td = t.double().view(B, G, -1)
+        return torch.stack([td.sum(-1), (td ** 2).sum(-1)], -1).reshape(-1).to(dev)
+    xd, rd = x.to(dev), r.to(dev)
+    got = ops.group_norm_apply(xd, g1.to(dev), b1.to(dev), G, stats(x), act="gelu", res=rd, res_mode=mode,
+                               res_norm=(stats(r), g2.to(dev), b2.to(dev)))
+    check(got, want, 1e-5, "fused residual norm")
+    two = ops.group_norm_apply(xd, g1.to(dev), b1.to(dev), G, stats(x), act="gelu", res_mode=mode,
+                               res=ops.group_norm_apply(rd, g2.to(dev), b2.to(dev), G, stats(r)))
+    check(got, two.cpu(), 2e-6, "fused vs two passes")
+
+
 @pytest.mark.parametrize("B,Cin,H,W,Cout,K,groups", [
     (3, 1, 64, 64, 32, 3, 32),        # Generic_UNet stem, InstanceNorm statistics (one group per channel)
     (2, 1, 256, 256, 64, 3, 8),       # flow encoder stem, GroupNorm(8)
