@@ -386,8 +386,27 @@ class StackedConvLayers(Module):
                       [ConvDropoutNormNonlin(cout, cout) for _ in range(num_convs - 1)]
 
     def forward(self, x, x2=None):
+        # A block whose output feeds only the next block of the stack leaves its InstanceNorm + LeakyReLU to that block's
+        # convolution (applied while the tile is staged, ops.conv2d_f16s_prenorm): one 8-byte-per-element pass less per pair.
+        pending = None                                   # (raw conv output, its statistics, its norm module)
         for i, b in enumerate(self.blocks):
-            x = b(x, x2=x2) if i == 0 else b(x)
+            last = i == len(self.blocks) - 1
+            if pending is not None:
+                raw, ws, norm = pending
+                B, C, H, W = raw.shape
+                coef = ops.group_norm_coef(ws, norm._p["weight"], norm._p["bias"], norm.groups, B, C, H * W, norm.eps)
+                y, ws_b = ops.conv2d_f16s_prenorm(raw, coef, 0.01, b.conv._wpk, b.conv._ws, b.conv._p.get("bias"), b.conv.cout,
+                                                  stats_groups=b.instnorm.groups)
+            else:
+                kw = {} if (x2 is None or i > 0) else {"x2": x2}
+                y, ws_b = b.conv(x, stats_groups=b.instnorm.groups, **kw)
+            nxt = None if last else self.blocks[i + 1]
+            if (nxt is not None and ws_b is not None and nxt.conv.ks == (3, 3) and nxt.conv.stride == 1 and getattr(nxt.conv, "_f16s", False)
+                    and ops.prenorm_ok(y, nxt.conv.cout)):
+                pending = (y, ws_b, b.instnorm)
+                continue
+            pending = None
+            x = b.instnorm(y, act="lrelu", ws=ws_b)
         return x
 
 

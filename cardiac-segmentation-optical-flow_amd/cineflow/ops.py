@@ -263,6 +263,33 @@ def conv2d_small_cin(x, weight, bias, stats_groups=None):
     return (out, ws) if stats_groups else out
 
 
+PRENORM = os.environ.get("CF_PRENORM", "1") != "0"        # 0: every normalisation runs as its own apply pass (A/B knob)
+
+
+def prenorm_ok(x, cout):
+    """can cf_conv2d_f16s_prenorm take this input (raw conv output [B,C,H,W]) for a 3x3 / stride 1 convolution to `cout` channels?"""
+    B, C, H, W = x.shape
+    return bool(PRENORM and CONV_MODE == "f16s" and x.data_ptr() % 16 == 0 and lib().cf_conv2d_f16s_prenorm_ok(B, C, H, W, cout) == 1)
+
+
+def group_norm_coef(ws, gamma, beta, groups, B, C, HW, eps=1e-5):
+    """{mean, rstd * gamma, beta} per (sample, channel) from a statistics workspace -> float [B,3,C] for conv2d_f16s_prenorm"""
+    coef = torch.empty((B, 3, C), dtype=torch.float32, device=ws.device)
+    check(lib().cf_group_norm_coef(ws.data_ptr(), _opt(gamma), _opt(beta), B, C, HW, groups, float(eps), _f32(coef), _stream()), "cf_group_norm_coef")
+    return coef
+
+
+def conv2d_f16s_prenorm(x, coef, slope, wpk, wscale, bias, cout, stats_groups=None):
+    """3x3 / stride 1 convolution of lrelu((x - mean) * scale + shift, slope): x is the producer's raw output, coef its
+    group_norm_coef.  Returns (out, ws) with stats_groups like conv2d_f16s."""
+    B, C, H, W = x.shape
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    ws = _zeroed_stats_ws(2 * B * stats_groups, x.device) if stats_groups else None
+    check(lib().cf_conv2d_f16s_prenorm(_f32(x), C, _f32(coef), float(slope), wpk.data_ptr(), _opt(bias), _f32(out), B, H, W, cout, 2.0 ** -wscale,
+                                       None if ws is None else ws.data_ptr(), -stats_groups if stats_groups else 0, _stream()), "cf_conv2d_f16s_prenorm")
+    return (out, ws) if stats_groups else out
+
+
 def conv_transpose2d_k2s2_f16s(x, wpk, wscale, bias, cout, out=None, out_coff=0, stats_groups=None):
     B, Cin, H, W = x.shape
     if out is None:

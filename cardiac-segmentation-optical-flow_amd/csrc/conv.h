@@ -21,6 +21,11 @@ struct ConvParams {
     double* gn_ws;        // optional: accumulate GroupNorm statistics of the OUTPUT (sum, sum of squares per (sample, group))
     int gn_groups;
     int gn_prezeroed = 0;   // gn_ws is already zero (caller-managed pool)
+    // optional: x1 is a raw convolution output whose normalisation + LeakyReLU has been deferred to this consumer (conv_f16s.hip,
+    // vector staging only): per (sample, channel) {mean, scale, shift}, float [B][3][C1]; value = lrelu((x - mean) * scale + shift)
+    const float* in_norm = nullptr;
+    float in_slope = 1.0f;
+    int probe = 0;          // 1: run the dispatch and its checks only, launch nothing (capability query)
 };
 
 // validates nothing; callers validate.  Returns CF_OK / CF_ERR_LAUNCH.

@@ -64,7 +64,7 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 // chunks of loads in flight, always one LDS buffer ahead.  vmcnt retires in issue order, so in the mixed design every
 // wait for a weight fragment also waited for the staging loads issued before it (ablating those loads made the kernel
 // 19-33 % faster); with separate roles nothing in the MFMA waves ever waits for HBM.
-template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC>
+template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE>
 __global__ void __launch_bounds__(64 * NW + 64 * NLW, NLW ? 5 : (NW == 8 ? 2 : ((NTW <= 2 && MAXT <= 3) ? 4 : ((NTW == 4 && WM == 4) ? 3 : 2))))
 conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restrict__ wpk) {
     constexpr int KW = (KHW == 9) ? 3 : 1;
@@ -238,18 +238,37 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
             }
         }
     };
+    // PRE: the input is a raw convolution output; its InstanceNorm / GroupNorm + LeakyReLU is applied here, between the load and the
+    // hi/lo split: v = lrelu((v - mean) * scale + shift) with the per-channel triples of this sample staged once in LDS behind the two
+    // patch buffers ([3][nchunk * CK] floats; channels past C1 hold zeros).  Padding quads (offset parked out of range) stay zero.
+    const float* ctab = reinterpret_cast<const float*>(lds + 2 * buf_bytes);
+    const int ctab_n = g.nchunk * CK;
     auto write_stage_v = [&](int chunk, const f32x4v (&stg)[VT][4]) {
 #pragma unroll
         for (int t = 0; t < VT; ++t) {
             unsigned char* base = lds + (chunk & 1) * buf_bytes + v_lds[t];
+            f32x4v cm = {0.f, 0.f, 0.f, 0.f}, ca = cm, cs = cm;
+            const bool valid = v_o1[t] != OOB;
+            if (PRE) {
+                const int c0 = chunk * CK + (int)v_c4[t];
+                cm = *reinterpret_cast<const f32x4v*>(ctab + c0);
+                ca = *reinterpret_cast<const f32x4v*>(ctab + ctab_n + c0);
+                cs = *reinterpret_cast<const f32x4v*>(ctab + 2 * ctab_n + c0);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (!((v_mask[t] >> k) & 1u)) continue;
                 f16x4 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    float v = stg[t][j][k];
+                    if (PRE) {
+                        v = (v - cm[j]) * ca[j] + cs[j];
+                        v = v > 0.f ? v : v * p.in_slope;
+                        v = valid ? v : 0.f;
+                    }
                     _Float16 h, l;
-                    split_f16(stg[t][j][k], h, l);
+                    split_f16(v, h, l);
                     hi[j] = h;
                     lo[j] = l;
                 }
@@ -326,6 +345,14 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
 
 #pragma unroll
     for (int sidx = 0; sidx < D; ++sidx) load_a(0, sidx, sidx % R);
+    if (PRE) {
+        float* ct = reinterpret_cast<float*>(lds + 2 * buf_bytes);
+        for (int k = tid; k < 3 * ctab_n; k += 64 * NW) {
+            const int which = k / ctab_n, c = k - which * ctab_n;
+            ct[k] = c < p.C1 ? p.in_norm[((long)b0 * 3 + which) * p.C1 + c] : 0.f;
+        }
+        __syncthreads();
+    }
     if (VEC) write_stage_v(0, stgv);
     else if (NLW == 0) write_stage(0, stg0);
     __syncthreads();
@@ -558,7 +585,7 @@ static int f16s_vec() {
     return v;
 }
 
-template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC>
+template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE = 0>
 static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s);
 
 // picks the vector-staging instantiation when the layer qualifies (stride 1, W % 4 == 0, 16-byte aligned inputs, one
@@ -573,14 +600,22 @@ static int launch_f16s(const ConvParams& p, F16sGeom g, const _Float16* wpk, hip
         const int nq = ((a + g.PW - 1) >> 2) + 1;
         const int tasks = (CK / 4) * g.NIMG * g.PH * nq;
         g.NQ = nq;
-        if (tasks <= 64 * NW) return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 1>(p, g, wpk, s);
+        if (tasks <= 64 * NW) {
+            if constexpr (MAXT == 2 && KHW == 9 && NLW == 0) {      // the stride-1 3x3 shapes: also built with the deferred input normalisation
+                if (p.in_norm && g.NIMG == 1 && p.C2 == 0 && (reinterpret_cast<uintptr_t>(p.in_norm) & 3) == 0)
+                    return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 1, 1>(p, g, wpk, s);
+            }
+            if (p.in_norm) { set_error("conv_f16s: deferred input normalisation is not built for this layer shape"); return CF_ERR_ARG; }
+            return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 1>(p, g, wpk, s);
+        }
         // (two tasks per thread for the (2 TH + 1) x (2 TW + 1) patches of the stride-2 shapes: measured equal or 2 % slower, not built)
         g.NQ = 0;
     }
+    if (p.in_norm) { set_error("conv_f16s: deferred input normalisation needs the vector staging path (3x3, stride 1, W % 4 == 0)"); return CF_ERR_ARG; }
     return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 0>(p, g, wpk, s);
 }
 
-template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC>
+template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE>
 static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s) {
     constexpr int REC = CK * 4 + 16;
     constexpr int NSTAGE = NLW ? 64 * NLW : 64 * NW;
@@ -603,12 +638,13 @@ static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, h
         set_error("conv_f16s: staging tasks exceed MAXT");
         return CF_ERR_ARG;
     }
-    const size_t lds_bytes = (size_t)2 * g.NIMG * g.PH * g.PWR * REC;
+    const size_t lds_bytes = (size_t)2 * g.NIMG * g.PH * g.PWR * REC + (PRE ? (size_t)3 * g.nchunk * CK * sizeof(float) : 0);
     if (lds_bytes > 160 * 1024) {
         set_error("conv_f16s: LDS tile too large");
         return CF_ERR_ARG;
     }
-    auto kern = conv_f16s_kernel<KHW, CK, WM, NTW, MAXT, NLW, NW, VEC>;
+    if (p.probe) return CF_OK;
+    auto kern = conv_f16s_kernel<KHW, CK, WM, NTW, MAXT, NLW, NW, VEC, PRE>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -808,6 +844,42 @@ extern "C" int cf_conv2d_f16s(const float* x1, int C1, const float* x2, int C2, 
     CF_REQUIRE(!gn_ws || (p.gn_groups > 0 && Cout % p.gn_groups == 0 && out_coff == 0 && out_ctotal == Cout), "bad GroupNorm statistics request");
     CF_REQUIRE(p.Ho > 0 && p.Wo > 0, "empty output");
     CF_REQUIRE(conv_f16s_supported(p), "unsupported configuration for the f16-split kernel (3x3 pad 1 or 1x1 pad 0, stride 1/2)");
+    return launch_conv_f16s(p, reinterpret_cast<const _Float16*>(wpk), as_stream(stream));
+}
+
+// cf_conv2d_f16s whose input x is a RAW convolution output with its InstanceNorm / GroupNorm + LeakyReLU deferred to this consumer
+// (the second convolution of a Generic_UNet stage): in_norm = float [B][3][C] {mean, scale, shift} from cf_group_norm_coef, applied
+// as lrelu((x - mean) * scale + shift, in_slope) while the tile is staged -- the producer's apply pass (8 B per element) disappears.
+// Built for 3x3 / stride 1 / pad 1 layers on the vector staging path (W % 4 == 0, one sample per workgroup, single input);
+// cf_conv2d_f16s_prenorm_ok answers whether a shape qualifies (1) or not (0).
+static void prenorm_params(ConvParams& p, const float* x, int C, const float* bias, float* out, int B, int H, int W, int Cout, float alpha,
+                           double* gn_ws, int gn_groups, const float* in_norm, float in_slope) {
+    p.x1 = x; p.x2 = nullptr; p.wt = nullptr; p.bias = bias; p.res = nullptr; p.out = out; p.w_bstride = 0;
+    p.C1 = C; p.C2 = 0; p.B = B; p.H = H; p.W = W; p.Cout = Cout; p.KH = 3; p.KW = 3; p.stride = 1;
+    p.pad_h = 1; p.pad_w = 1; p.Ho = H; p.Wo = W; p.out_ctotal = Cout; p.out_coff = 0; p.act = CF_ACT_NONE; p.alpha = alpha; p.scatter2x2 = 0;
+    p.gn_ws = gn_ws; p.gn_groups = gn_groups < 0 ? -gn_groups : gn_groups; p.gn_prezeroed = gn_groups < 0;
+    p.in_norm = in_norm; p.in_slope = in_slope;
+}
+
+extern "C" int cf_conv2d_f16s_prenorm_ok(int B, int C, int H, int W, int Cout) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    ConvParams p;
+    float* dummy = reinterpret_cast<float*>(uintptr_t(256));      // never dereferenced: probe mode launches nothing
+    prenorm_params(p, dummy, C, nullptr, dummy, B, H, W, Cout, 1.f, nullptr, 0, dummy, 0.01f);
+    p.probe = 1;
+    if (!conv_f16s_supported(p)) return 0;
+    return launch_conv_f16s_impl(p, reinterpret_cast<const _Float16*>(dummy), nullptr, nullptr) == CF_OK ? 1 : 0;
+}
+
+extern "C" int cf_conv2d_f16s_prenorm(const float* x, int C, const float* in_norm, float in_slope, const void* wpk, const float* bias, float* out,
+                                      int B, int H, int W, int Cout, float alpha, double* gn_ws, int gn_groups, void* stream) {
+    CF_REQUIRE(x && wpk && out && in_norm, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && Cout > 0, "bad shape B=%d C=%d H=%d W=%d Cout=%d", B, C, H, W, Cout);
+    CF_REQUIRE((reinterpret_cast<uintptr_t>(wpk) & 15) == 0, "packed weights must be 16-byte aligned");
+    ConvParams p;
+    prenorm_params(p, x, C, bias, out, B, H, W, Cout, alpha, gn_ws, gn_groups, in_norm, in_slope);
+    CF_REQUIRE(!gn_ws || (p.gn_groups > 0 && Cout % p.gn_groups == 0), "bad GroupNorm statistics request");
+    CF_REQUIRE(conv_f16s_supported(p), "unsupported configuration for the f16-split kernel");
     return launch_conv_f16s(p, reinterpret_cast<const _Float16*>(wpk), as_stream(stream));
 }
 

@@ -323,6 +323,33 @@ extern "C" int cf_group_norm_apply(const float* x, const float* gamma, const flo
     return gn_apply_launch(x, gamma, beta, res, out, B, C, HW, groups, eps, act, res_mode, ws, as_stream(stream));
 }
 
+// {mean, scale, shift} per (sample, channel) from the fp64 sums: what a consumer needs to apply the normalisation itself
+// (cf_conv2d_f16s_prenorm): y = (x - mean) * scale + shift, scale = rstd * gamma, shift = beta.  coef float [B][3][C].
+__global__ void __launch_bounds__(256) gn_coef_kernel(const double* __restrict__ ws, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      int B, int C, int HW, int groups, float eps, float* __restrict__ coef) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C, cpg = C / groups;
+    const long slab = (long)b * groups + c / cpg;
+    const double invL = 1.0 / ((double)cpg * HW);
+    const double mean = ws[2 * slab] * invL;
+    double var = ws[2 * slab + 1] * invL - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float* o = coef + (long)b * 3 * C + c;
+    o[0] = (float)mean;
+    o[C] = (float)(1.0 / sqrt(var + (double)eps)) * (gamma ? gamma[c] : 1.f);
+    o[2 * C] = beta ? beta[c] : 0.f;
+}
+
+extern "C" int cf_group_norm_coef(const double* ws, const float* gamma, const float* beta, int B, int C, int HW, int groups, float eps, float* coef,
+                                  void* stream) {
+    CF_REQUIRE(ws && coef, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && HW > 0 && groups > 0 && C % groups == 0 && (long)B * C < (1L << 31), "bad shape B=%d C=%d HW=%d groups=%d", B, C, HW, groups);
+    hipLaunchKernelGGL(gn_coef_kernel, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, as_stream(stream), ws, gamma, beta, B, C, HW, groups, eps, coef);
+    CF_CHECK_LAUNCH();
+    return CF_OK;
+}
+
 // cf_group_norm_apply with a residual that still awaits its own GroupNorm (same group count and eps): res_ws holds the residual's
 // (sum, sum of squares) pairs, res_gamma / res_beta its affine parameters.
 extern "C" int cf_group_norm_apply_res_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,

@@ -149,6 +149,17 @@ int cf_group_norm_apply(const float* x, const float* gamma, const float* beta, c
 int cf_group_norm_apply_res_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,
                                  int HW, int groups, float eps, int act, int res_mode, const double* ws, const double* res_ws,
                                  const float* res_gamma, const float* res_beta, void* stream);
+/* Deferred normalisation: instead of running the apply pass on a convolution output, hand its per-(sample, channel) coefficients to
+ * the consuming convolution.  cf_group_norm_coef: ws ({sum, sum of squares} pairs) -> coef float [B][3][C] = {mean, rstd * gamma,
+ * beta}.  cf_conv2d_f16s_prenorm: 3x3 / stride 1 / pad 1 convolution of lrelu((x - mean) * scale + shift, in_slope) -- the second
+ * convolution of a Generic_UNet stage, nnunet/network_architecture/generic_UNet.py:79-144, consuming the first one's raw output --
+ * dense output, optional fused statistics as in cf_conv2d_f16s.  Built for the vector-staging layer shapes only;
+ * cf_conv2d_f16s_prenorm_ok(B, C, H, W, Cout) returns 1 when a shape qualifies (no launch), and the call fails otherwise. */
+int cf_group_norm_coef(const double* ws, const float* gamma, const float* beta, int B, int C, int HW, int groups, float eps, float* coef,
+                       void* stream);
+int cf_conv2d_f16s_prenorm_ok(int B, int C, int H, int W, int Cout);
+int cf_conv2d_f16s_prenorm(const float* x, int C, const float* in_norm, float in_slope, const void* wpk, const float* bias, float* out,
+                           int B, int H, int W, int Cout, float alpha, double* gn_ws, int gn_groups, void* stream);
 
 /* nn.LayerNorm(C) over the channel axis of channel-first tokens x [B,C,N] (lib/vit_transformer.py:1257,1261,1265);
  * the residual add is done by the preceding conv epilogue. */

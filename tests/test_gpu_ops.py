@@ -354,6 +354,45 @@ def test_conv_f16s_many_tiles(dev, B, C1, C2, H, W, Cout, groups):
     assert float(big[:, :8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,C,H,W,Cout", [
+    (3, 32, 64, 64, 32),       # narrow shape (Generic_UNet level 0)
+    (2, 64, 48, 64, 64),       # 64-channel shape, ragged rows
+    (2, 128, 32, 32, 128),     # 128-channel shapes
+    (9, 256, 32, 32, 256),     # >= 1024 workgroups x 2 channel blocks: the four-wave shape
+    (2, 480, 16, 16, 480),     # channel tail (480 = 30 chunks), 16-wide rows
+])
+def test_conv_f16s_prenorm(dev, B, C, H, W, Cout):
+    """convolution that applies its input's deferred InstanceNorm + LeakyReLU while staging, against torch on the materialised
+    activation; fused output statistics; the capability query"""
+    from cineflow import ops
+    x = randn(B, C, H, W, seed=100) * 1.7 + 0.4
+    g, bt = randn(C, seed=101), randn(C, seed=102)
+    w = randn(Cout, C, 3, 3, seed=103) / math.sqrt(C * 9)
+    b = randn(Cout, seed=104)
+    act = F.leaky_relu(F.instance_norm(x, weight=g, bias=bt, eps=1e-5), 0.01)
+    want = F.conv2d(act, w, b, padding=1)
+    xd = x.to(dev)
+    assert ops.prenorm_ok(xd, Cout)
+    xs = x.double().view(B, C, -1)
+    ws = torch.stack([xs.sum(-1), (xs ** 2).sum(-1)], -1).reshape(-1).to(dev)
+    coef = ops.group_norm_coef(ws, g.to(dev), bt.to(dev), C, B, C, H * W)
+    check(coef[:, 0], x.view(B, C, -1).mean(-1), 1e-6, "coef mean")
+    wpk, wsc = ops.pack_conv_weight_f16s(w.to(dev))
+    out, st = ops.conv2d_f16s_prenorm(xd, coef, 0.01, wpk, wsc, b.to(dev), Cout, stats_groups=Cout)
+    check(out, want, 3e-5, "prenorm conv")
+    yo = out.cpu().double().view(B, Cout, -1)
+    wst = torch.stack([yo.sum(-1), (yo ** 2).sum(-1)], -1)
+    assert float(((st.cpu().view(B, Cout, 2) - wst).abs() / (yo.abs().sum(-1)[..., None] + 1.0)).max()) <= 2e-6
+    # identical to the two-kernel path on the same operands
+    two = ops.conv2d_f16s(ops.group_norm_apply(xd, g.to(dev), bt.to(dev), C, ws, act="lrelu", out=torch.empty_like(xd)), wpk, wsc, b.to(dev), Cout, 3, 3, 1,
+                          (1, 1))
+    check(out, two.cpu(), 2e-5, "prenorm vs apply + conv")
+    assert not ops.prenorm_ok(torch.empty(2, 32, 30, 30, device=dev), 32)          # W % 4 != 0: scalar staging
+    assert not ops.prenorm_ok(torch.empty(4, 480, 8, 8, device=dev), 480)          # several samples per workgroup
+    with pytest.raises(RuntimeError):
+        ops.conv2d_f16s_prenorm(torch.zeros(2, 32, 30, 30, device=dev), coef[:2, :, :32].contiguous(), 0.01, wpk, wsc, None, Cout)
+
+
 @pytest.mark.parametrize("B,C,H,W", [(2, 64, 64, 64), (3, 32, 16, 16), (2, 16, 9, 7)])
 @pytest.mark.parametrize("mode", ["after_act", "before_act"])
 def test_group_norm_apply_res_norm(dev, B, C, H, W, mode):
