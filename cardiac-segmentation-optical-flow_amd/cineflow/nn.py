@@ -288,6 +288,7 @@ class InstanceNorm3d(Module):
         return y.view(B, C, D, H, W)
 
 # --------------------------------------------------------------------------------------------- lib/utils.py blocks
+PRENORM_GELU = os.environ.get("CF_PRENORM_GELU", "1") != "0"       # 0: GELU(GN1(conv1)) is materialised by its own apply pass (A/B knob)
 FUSE_RES_NORM = os.environ.get("CF_FUSE_RES_NORM", "1") != "0"     # 0: the downsample branch's GroupNorm runs as its own pass (A/B knob)
 
 
@@ -306,21 +307,37 @@ class DoubleConv(Module):
         if self.has_ds:
             self.downsample = {0: Conv2d(in_dim, out_dim, 1, stride=stride), 1: GroupNorm(8, out_dim)}
 
+    def _conv2(self, t_raw, ws1):
+        """conv2 on GELU(GN1(t_raw)) with the normalisation applied while conv2 stages its input -> (raw conv2 output, its statistics)"""
+        B, C, H, W = t_raw.shape
+        coef = ops.group_norm_coef(ws1, self.norm1._p["weight"], self.norm1._p["bias"], self.norm1.groups, B, C, H * W, self.norm1.eps)
+        return ops.conv2d_f16s_prenorm(t_raw, coef, -1.0, self.conv2._wpk, self.conv2._ws, self.conv2._p.get("bias"), self.conv2.cout,
+                                       stats_groups=self.norm2.groups)
+
     def forward(self, x, x2=None):
-        t = conv_norm(self.conv1, self.norm1, x, x2=x2, act="gelu")
+        kw1 = {} if x2 is None else {"x2": x2}
+        t, ws1 = self.conv1(x, stats_groups=self.norm1.groups, **kw1)
+        pre = (PRENORM_GELU and ws1 is not None and self.conv2.ks == (3, 3) and self.conv2.stride == 1 and getattr(self.conv2, "_f16s", False)
+               and ops.prenorm_ok(t, self.conv2.cout))
+        if pre:
+            y2, ws2 = self._conv2(t, ws1)
+            conv2 = lambda **k: self.norm2(y2, act="gelu", ws=ws2, **k)                       # noqa: E731
+        else:
+            t = self.norm1(t, act="gelu", ws=ws1)
+            conv2 = lambda **k: conv_norm(self.conv2, self.norm2, t, act="gelu", **k)          # noqa: E731
         if not self.residual:
-            return conv_norm(self.conv2, self.norm2, t, act="gelu")
+            return conv2()
         if self.has_ds:
             # the branch's GroupNorm rides in the final apply pass: GELU(GN2(conv2(t))) + GN_ds(conv1x1(x)) in one kernel
             kw = {} if x2 is None else {"x2": x2}
             r, ws_r = self.downsample[0](x, stats_groups=self.downsample[1].groups, **kw)
             if FUSE_RES_NORM:
-                return conv_norm(self.conv2, self.norm2, t, act="gelu", res=r, res_mode="after_act", res_norm=(ws_r, self.downsample[1]))
+                return conv2(res=r, res_mode="after_act", res_norm=(ws_r, self.downsample[1]))
             r = self.downsample[1](r, ws=ws_r)
         else:
             assert x2 is None
             r = x
-        return conv_norm(self.conv2, self.norm2, t, act="gelu", res=r, res_mode="after_act")
+        return conv2(res=r, res_mode="after_act")
 
 
 class SingleConv(Module):

@@ -24,7 +24,7 @@ struct ConvParams {
     // optional: x1 is a raw convolution output whose normalisation + LeakyReLU has been deferred to this consumer (conv_f16s.hip,
     // vector staging only): per (sample, channel) {mean, scale, shift}, float [B][3][C1]; value = lrelu((x - mean) * scale + shift)
     const float* in_norm = nullptr;
-    float in_slope = 1.0f;
+    float in_slope = 1.0f;   // LeakyReLU slope; in_slope < 0 selects GELU (erf form) instead
     int probe = 0;          // 1: run the dispatch and its checks only, launch nothing (capability query)
 };
 

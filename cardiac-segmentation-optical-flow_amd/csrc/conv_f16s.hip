@@ -264,7 +264,7 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
                     float v = stg[t][j][k];
                     if (PRE) {
                         v = (v - cm[j]) * ca[j] + cs[j];
-                        v = v > 0.f ? v : v * p.in_slope;
+                        v = p.in_slope < 0.f ? 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)) : (v > 0.f ? v : v * p.in_slope);
                         v = valid ? v : 0.f;
                     }
                     _Float16 h, l;

@@ -151,7 +151,8 @@ int cf_group_norm_apply_res_norm(const float* x, const float* gamma, const float
                                  const float* res_gamma, const float* res_beta, void* stream);
 /* Deferred normalisation: instead of running the apply pass on a convolution output, hand its per-(sample, channel) coefficients to
  * the consuming convolution.  cf_group_norm_coef: ws ({sum, sum of squares} pairs) -> coef float [B][3][C] = {mean, rstd * gamma,
- * beta}.  cf_conv2d_f16s_prenorm: 3x3 / stride 1 / pad 1 convolution of lrelu((x - mean) * scale + shift, in_slope) -- the second
+ * beta}.  cf_conv2d_f16s_prenorm: 3x3 / stride 1 / pad 1 convolution of lrelu((x - mean) * scale + shift, in_slope) (in_slope < 0:
+ * GELU, for the second convolution of a DoubleConv, nnunet/lib/utils.py:1182-1215) -- the second
  * convolution of a Generic_UNet stage, nnunet/network_architecture/generic_UNet.py:79-144, consuming the first one's raw output --
  * dense output, optional fused statistics as in cf_conv2d_f16s.  Built for the vector-staging layer shapes only;
  * cf_conv2d_f16s_prenorm_ok(B, C, H, W, Cout) returns 1 when a shape qualifies (no launch), and the call fails otherwise. */

@@ -387,6 +387,12 @@ def test_conv_f16s_prenorm(dev, B, C, H, W, Cout):
     two = ops.conv2d_f16s(ops.group_norm_apply(xd, g.to(dev), bt.to(dev), C, ws, act="lrelu", out=torch.empty_like(xd)), wpk, wsc, b.to(dev), Cout, 3, 3, 1,
                           (1, 1))
     check(out, two.cpu(), 2e-5, "prenorm vs apply + conv")
+    # the DoubleConv form: GroupNorm(8) + GELU (in_slope < 0) deferred to the consumer
+    xg = x.double().view(B, 8, -1)
+    wsg = torch.stack([xg.sum(-1), (xg ** 2).sum(-1)], -1).reshape(-1).to(dev)
+    coefg = ops.group_norm_coef(wsg, g.to(dev), bt.to(dev), 8, B, C, H * W)
+    wantg = F.conv2d(F.gelu(F.group_norm(x, 8, g, bt, eps=1e-5)), w, b, padding=1)
+    check(ops.conv2d_f16s_prenorm(xd, coefg, -1.0, wpk, wsc, b.to(dev), Cout), wantg, 3e-5, "prenorm conv, GroupNorm + GELU")
     assert not ops.prenorm_ok(torch.empty(2, 32, 30, 30, device=dev), 32)          # W % 4 != 0: scalar staging
     assert not ops.prenorm_ok(torch.empty(4, 480, 8, 8, device=dev), 480)          # several samples per workgroup
     with pytest.raises(RuntimeError):
