@@ -53,18 +53,6 @@ struct F16sGeom {
 __host__ __device__ inline unsigned f16s_magic(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
 __device__ __forceinline__ int fdiv(int n, int d, unsigned m) { return d <= 1 ? n : (int)__umulhi((unsigned)n, m); }
 
-// GELU for the deferred-normalisation staging path: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. fp32
-// rounding level on 0.5 x (1 + erf)): one rcp, one exp and eight FMAs with no branch, about a third of the library erff's
-// instructions -- this code runs once per staged element inside the convolution's main loop.
-__device__ __forceinline__ float gelu_staging(float v) {
-    const float z = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    const float erf_abs = fmaf(-poly, e, 1.0f);
-    return 0.5f * v * (1.0f + copysignf(erf_abs, v));
-}
-
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     x = __builtin_amdgcn_fmed3f(x, -60000.f, 60000.f);  // one v_med3_f32: keeps huge inputs finite in fp16
     hi = (_Float16)x;
@@ -276,7 +264,7 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
                     float v = stg[t][j][k];
                     if (PRE) {
                         v = (v - cm[j]) * ca[j] + cs[j];
-                        v = p.in_slope < 0.f ? gelu_staging(v) : (v > 0.f ? v : v * p.in_slope);
+                        v = p.in_slope < 0.f ? gelu_as(v) : (v > 0.f ? v : v * p.in_slope);
                         v = valid ? v : 0.f;
                     }
                     _Float16 h, l;
