@@ -601,7 +601,10 @@ static int launch_f16s(const ConvParams& p, F16sGeom g, const _Float16* wpk, hip
         const int tasks = (CK / 4) * g.NIMG * g.PH * nq;
         g.NQ = nq;
         if (tasks <= 64 * NW) {
-            if constexpr (MAXT == 2 && KHW == 9 && NLW == 0) {      // the stride-1 3x3 shapes: also built with the deferred input normalisation
+            // the stride-1 3x3 four-wave shapes are also built with the deferred input normalisation; not the 8-wave shape of the small
+            // maps (< 1024 workgroups): its short workgroups lose more to the table fill + barrier than the apply pass costs
+            // (256 channels at 32x32, B = 32: 192 us vs 120 + 15 us, tools/prenorm_ab.py)
+            if constexpr (MAXT == 2 && KHW == 9 && NLW == 0 && NW == 4) {
                 if (p.in_norm && g.NIMG == 1 && p.C2 == 0 && (reinterpret_cast<uintptr_t>(p.in_norm) & 3) == 0)
                     return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 1, 1>(p, g, wpk, s);
             }
