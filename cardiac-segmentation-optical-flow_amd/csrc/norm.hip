@@ -58,6 +58,11 @@ __global__ void __launch_bounds__(256) gn_stats_block_kernel(const float* __rest
     }
 }
 
+// streaming (non-temporal) accesses of the large-plane apply pass: every element is touched exactly once by this kernel
+typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+#define NT_LOAD4(p) ([&]() { const nt_f32x4 _v = __builtin_nontemporal_load(reinterpret_cast<const nt_f32x4*>(p)); return make_float4(_v.x, _v.y, _v.z, _v.w); }())
+#define NT_STORE4(p, a, b, c, d) __builtin_nontemporal_store(nt_f32x4{a, b, c, d}, reinterpret_cast<nt_f32x4*>(p))
+
 // optional normalisation of the residual operand (all NULL: the residual is added as it is)
 struct ResNorm {
     const double* ws;
@@ -103,9 +108,9 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
         const float4* r4 = res ? reinterpret_cast<const float4*>(res + base) : nullptr;
         float4* o4 = reinterpret_cast<float4*>(out + base);
         for (int i = seg * 256 + threadIdx.x; i < n4; i += segs * 256) {
-            float4 v = x4[i];
+            float4 v = NT_LOAD4(x4 + i);
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (res_mode != CF_RES_NONE) r = r4[i];
+            if (res_mode != CF_RES_NONE) r = NT_LOAD4(r4 + i);
             float t[4] = {v.x, v.y, v.z, v.w};
             const float rr[4] = {(r.x - rm) * ra + rb, (r.y - rm) * ra + rb, (r.z - rm) * ra + rb, (r.w - rm) * ra + rb};
 #pragma unroll
@@ -116,7 +121,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(const float* __restrict__
                 if (res_mode == CF_RES_AFTER_ACT) y += rr[k];
                 t[k] = y;
             }
-            o4[i] = make_float4(t[0], t[1], t[2], t[3]);
+            NT_STORE4(o4 + i, t[0], t[1], t[2], t[3]);
         }
     } else {
         for (int i = seg * 256 + threadIdx.x; i < HW; i += segs * 256) {
