@@ -92,6 +92,7 @@ SIGNATURES = {
     "cf_region_stats": [P, P, L, I, P, P],
     "cf_spatial_gradient3d": [P, P, L, I, I, I, P],
     "cf_slab_abs_sum": [P, I, I, I, L, P, P],
+    "cf_ssim_map": [P, P, I, I, I, DBL, DBL, DBL, P, P],
     "cf_profile_enable": [I],
     "cf_profile_reset": [],
     "cf_profile_read": [I, P, P, P],

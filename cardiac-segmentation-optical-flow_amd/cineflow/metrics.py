@@ -376,3 +376,36 @@ def gradient_means(slice_flow):
     check(lib().cf_slab_abs_sum(_f32(g), 6, 1, T, H * W, sums.data_ptr(), _stream()), "cf_slab_abs_sum")
     s = sums.cpu().numpy().reshape(2, 3, T)
     return s[:, 2].sum(0) / (2 * H * W), s[:, :2].sum((0, 1)) / (4 * H * W)
+
+
+# ------------------------------------------------------------------------------------------------ compute_SSIM*.py
+def structural_similarity(im1, im2, *, win_size=None, data_range=None, full=False, K1=0.01, K2=0.03, use_sample_covariance=True):
+    """skimage.metrics.structural_similarity as nnunet/compute_SSIM.py:91 and compute_SSIM_crop_per_structure.py:88 call it: 2-D
+    images, uniform win_size x win_size window (default 7), `data_range` given.  Computed in fp64 (skimage keeps float32 inputs in
+    float32).  Returns the mean SSIM over the interior (the map cropped by (win_size - 1) // 2), and with full=True also the map."""
+    a = (im1 if torch.is_tensor(im1) else torch.from_numpy(np.ascontiguousarray(im1))).to(_dev(), dtype=torch.float64).contiguous()
+    b = (im2 if torch.is_tensor(im2) else torch.from_numpy(np.ascontiguousarray(im2))).to(_dev(), dtype=torch.float64).contiguous()
+    assert_shape(a, b)
+    if a.dim() != 2:
+        raise NotImplementedError("structural_similarity is built for 2-D images (the reference scores slice by slice)")
+    if data_range is None:
+        raise ValueError("data_range must be given for floating-point images (as skimage requires)")
+    win = 7 if win_size is None else int(win_size)
+    H, W = a.shape
+    if win % 2 == 0 or win > min(H, W):
+        raise ValueError("win_size must be odd and no larger than the image")
+    NP = win * win
+    cov_norm = NP / (NP - 1.0) if use_sample_covariance else 1.0
+    R = float(data_range)
+    S = torch.empty((H, W), dtype=torch.float64, device=a.device)
+    check(lib().cf_ssim_map(a.data_ptr(), b.data_ptr(), H, W, win, (K1 * R) ** 2, (K2 * R) ** 2, cov_norm, S.data_ptr(), _stream()), "cf_ssim_map")
+    pad = (win - 1) // 2
+    inner = S[pad:H - pad, pad:W - pad].contiguous()
+    zeros = torch.zeros(inner.numel(), dtype=torch.uint8, device=a.device)
+    st = torch.empty(3, dtype=torch.float64, device=a.device)
+    check(lib().cf_region_stats(inner.data_ptr(), _u8(zeros), inner.numel(), 1, st.data_ptr(), _stream()), "cf_region_stats")
+    s, cnt, _ = st.cpu().tolist()
+    mssim = s / cnt
+    if full:
+        return mssim, (S if torch.is_tensor(im1) else S.cpu().numpy())
+    return mssim

@@ -179,6 +179,34 @@ __global__ void __launch_bounds__(256) slab_abs_sum_kernel(const float* __restri
     if (threadIdx.x == 0) atomicAdd(&sums[slab], r[0] + r[1] + r[2] + r[3]);
 }
 
+// skimage.metrics.structural_similarity (uniform window, use_sample_covariance) of nnunet/compute_SSIM*.py: the five local means
+// (x, y, xx, yy, xy over a win x win window, scipy 'reflect' boundary) and the SSIM value of every pixel, in fp64.
+__global__ void __launch_bounds__(256) ssim_map_kernel(const double* __restrict__ a, const double* __restrict__ b, int H, int W, int win, double C1,
+                                                       double C2, double cov_norm, double* __restrict__ S) {
+    const long n = (long)H * W;
+    const int r = win / 2;
+    const double inv = 1.0 / ((double)win * win);
+    GRID_STRIDE(i, n) {
+        const int y = (int)(i / W), x = (int)(i - (long)y * W);
+        double sx = 0.0, sy = 0.0, sxx = 0.0, syy = 0.0, sxy = 0.0;
+        for (int dy = -r; dy <= r; ++dy) {
+            int yy = y + dy;
+            yy = yy < 0 ? -yy - 1 : (yy >= H ? 2 * H - 1 - yy : yy);       // reflect: (d c b a | a b c d | d c b a)
+            yy = min(max(yy, 0), H - 1);
+            for (int dx = -r; dx <= r; ++dx) {
+                int xx = x + dx;
+                xx = xx < 0 ? -xx - 1 : (xx >= W ? 2 * W - 1 - xx : xx);
+                xx = min(max(xx, 0), W - 1);
+                const double u = a[(long)yy * W + xx], v = b[(long)yy * W + xx];
+                sx += u; sy += v; sxx += u * u; syy += v * v; sxy += u * v;
+            }
+        }
+        const double ux = sx * inv, uy = sy * inv;
+        const double vx = cov_norm * (sxx * inv - ux * ux), vy = cov_norm * (syy * inv - uy * uy), vxy = cov_norm * (sxy * inv - ux * uy);
+        S[i] = ((2.0 * ux * uy + C1) * (2.0 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+    }
+}
+
 }  // namespace cf
 
 using namespace cf;
@@ -264,6 +292,15 @@ extern "C" int cf_slab_abs_sum(const float* x, int C, int A, int S, long B, doub
     if (k < 1) k = 1;
     if (k > 64) k = 64;
     hipLaunchKernelGGL(slab_abs_sum_kernel, dim3((unsigned)(C * S), (unsigned)k), dim3(256), 0, s, x, A, S, B, sums);
+    CF_CHECK_LAUNCH();
+    return CF_OK;
+}
+
+extern "C" int cf_ssim_map(const double* im1, const double* im2, int H, int W, int win, double C1, double C2, double cov_norm, double* S, void* stream) {
+    CF_REQUIRE(im1 && im2 && S, "null pointer");
+    CF_REQUIRE(H > 0 && W > 0 && win >= 3 && (win & 1) && win <= H && win <= W, "bad shape H=%d W=%d win=%d (odd window no larger than the image)", H, W, win);
+    const long n = (long)H * W;
+    hipLaunchKernelGGL(ssim_map_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, as_stream(stream), im1, im2, H, W, win, C1, C2, cov_norm, S);
     CF_CHECK_LAUNCH();
     return CF_OK;
 }

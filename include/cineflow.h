@@ -294,6 +294,10 @@ int cf_region_stats(const double* x, const uint8_t* labels, long n, int K, doubl
  * (c, s) of x [C][A][S][B] -> sums fp64 [C*S] behind the per-frame means of :147-159. */
 int cf_spatial_gradient3d(const float* x, float* out, long N, int D, int H, int W, void* stream);
 int cf_slab_abs_sum(const float* x, int C, int A, int S, long B, double* sums, void* stream);
+/* skimage.metrics.structural_similarity as nnunet/compute_SSIM.py:91 calls it (2-D, uniform win x win window, sample covariance):
+ * S (fp64 [H][W]) = SSIM of every pixel from the five local means with scipy's 'reflect' boundary; C1 = (K1 R)^2, C2 = (K2 R)^2,
+ * cov_norm = NP / (NP - 1).  The mean over the interior (cf_region_stats on the cropped map) is the score. */
+int cf_ssim_map(const double* im1, const double* im2, int H, int W, int win, double C1, double C2, double cov_norm, double* S, void* stream);
 
 /* ---------------------------------------------------------------- measurement hooks (bench.py only; no reference analogue)
  * cf_profile_enable(n): pre-create n event pairs and time every conv / CorrVolume launch with a (start, stop) pair that

@@ -185,3 +185,21 @@ def gradient_means(slice_flow):
     gxy, gz = g[:, :, :2], g[:, :, 2]
     T = slice_flow.shape[0]
     return np.array([gz[:, :, t].mean() for t in range(T)]), np.array([gxy[:, :, :, t].mean() for t in range(T)])
+
+
+# --------------------------------------------------------------------------- compute_SSIM*.py (skimage absent: parity unpinned)
+def structural_similarity(im1, im2, data_range, win_size=7, full=False, K1=0.01, K2=0.03):
+    """skimage.metrics.structural_similarity (scikit-image >= 0.19; uniform window, use_sample_covariance=True) restated on
+    scipy.ndimage.uniform_filter, in float64."""
+    from scipy.ndimage import uniform_filter
+    im1, im2 = np.asarray(im1, dtype=np.float64), np.asarray(im2, dtype=np.float64)
+    NP = win_size ** im1.ndim
+    cov_norm = NP / (NP - 1)
+    ux, uy = uniform_filter(im1, size=win_size), uniform_filter(im2, size=win_size)
+    uxx, uyy, uxy = uniform_filter(im1 * im1, size=win_size), uniform_filter(im2 * im2, size=win_size), uniform_filter(im1 * im2, size=win_size)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
+    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+    pad = (win_size - 1) // 2
+    mssim = S[pad:-pad, pad:-pad].mean(dtype=np.float64)
+    return (mssim, S) if full else mssim

@@ -131,3 +131,35 @@ def test_jacobian_statistics_device(dev, golden):
     from oracle import metrics as OM
     x = np.random.default_rng(1).normal(size=(2, 2, 3, 9, 8)).astype(np.float32)
     same(M.spatial_gradient3d(x), OM.spatial_gradient3d(x), 1e-7)
+
+
+def test_oracle_ssim_properties():
+    """the restated SSIM (skimage absent): identical images score 1, the score is symmetric and falls with noise"""
+    from oracle import metrics as OM
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(40, 36)) * 50 + 200
+    assert abs(OM.structural_similarity(a, a, data_range=np.ptp(a)) - 1.0) < 1e-12
+    b, c = a + rng.normal(size=a.shape) * 5, a + rng.normal(size=a.shape) * 25
+    sb, sc = OM.structural_similarity(a, b, data_range=np.ptp(b)), OM.structural_similarity(a, c, data_range=np.ptp(b))
+    assert 1.0 > sb > sc > 0.0 and abs(OM.structural_similarity(b, a, data_range=np.ptp(b)) - sb) < 1e-12
+
+
+@pytest.mark.gpu
+def test_ssim_device(dev):
+    """device SSIM (compute_SSIM*.py) against the scipy restatement: score and full map, odd sizes, a non-default window"""
+    from cineflow import metrics as M
+    from oracle import metrics as OM
+    rng = np.random.default_rng(4)
+    for shape, win in (((64, 48), 7), ((33, 41), 7), ((20, 19), 11)):
+        a = rng.normal(size=shape) * 40 + 300
+        b = a + rng.normal(size=shape) * 12
+        dr = b.max() - b.min()
+        want, wmap = OM.structural_similarity(a, b, data_range=dr, win_size=win, full=True)
+        got, gmap = M.structural_similarity(a, b, data_range=dr, win_size=win, full=True)
+        assert abs(got - want) <= 1e-10 and float(np.abs(gmap - wmap).max()) <= 1e-9
+        assert abs(M.structural_similarity(a.astype(np.float32), b.astype(np.float32), data_range=dr, win_size=win) - want) <= 1e-5
+    assert abs(M.structural_similarity(a, a, data_range=1.0, win_size=11) - 1.0) <= 1e-12
+    with pytest.raises(ValueError):
+        M.structural_similarity(a, b)
+    with pytest.raises(NotImplementedError):
+        M.structural_similarity(np.zeros((3, 9, 9)), np.zeros((3, 9, 9)), data_range=1.0)
