@@ -65,7 +65,7 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 // wait for a weight fragment also waited for the staging loads issued before it (ablating those loads made the kernel
 // 19-33 % faster); with separate roles nothing in the MFMA waves ever waits for HBM.
 template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE>
-__global__ void __launch_bounds__(64 * NW + 64 * NLW, NLW ? 5 : (NW == 8 ? 2 : ((NTW <= 2 && MAXT <= 3) ? 4 : ((NTW == 4 && WM == 4) ? 3 : 2))))
+__global__ void __launch_bounds__(64 * NW + 64 * NLW, NLW ? 5 : (NW == 8 ? 2 : ((NTW <= 2 && MAXT <= 3) ? 4 : 2)))
 conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restrict__ wpk) {
     constexpr int KW = (KHW == 9) ? 3 : 1;
     constexpr int KS = CK / 16;            // MFMA k-steps per tap per chunk
@@ -792,7 +792,7 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     if (wide && k3) {
         // Two 128-channel shapes.  Four waves, each ONE m-tile x FOUR pixel tiles: a weight fragment feeds 12 MFMAs instead of 6, which
         // halves the per-wave weight re-reads from L1/L2 -- the resource the time stamps and the persistent-kernel experiment pointed at
-        // (+9-15 % on the 128- and 256-channel layers at 64x64 and above); 168 VGPRs, 3 waves/SIMD.  With few workgroups (32x32 maps)
+        // (+9-15 % on the 128- and 256-channel layers at 64x64 and above); 148 VGPRs (no scratch under a 2-workgroup launch bound; a bound of 3 made the allocator spill 168 B/lane for the same speed), 3 waves/SIMD.  With few workgroups (32x32 maps)
         // the 8-wave shape (4 m-tiles x 2 pixel groups, 4 waves/SIMD) keeps more of the chip busy.  CF_F16S_WIDE=2 / 3 force one.
         const long nwg = (long)g.tiles_x * g.tiles_y * g.bgroups * (p.Cout / 128);
         const int mode = f16s_wide();
