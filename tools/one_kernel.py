@@ -31,4 +31,15 @@ elif kind == "gn":
     gam, bet = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     for _ in range(5):
         ops.group_norm(x, gam, bet, groups, act="gelu", inplace=False) if False else ops.group_norm(x, gam, bet, groups, act="gelu", out=torch.empty_like(x))
+elif kind == "prenorm":      # python tools/one_kernel.py prenorm C H B gelu|lrelu
+    C, H, B = (int(v) for v in sys.argv[2:5])
+    act = sys.argv[5] if len(sys.argv) > 5 else "gelu"
+    groups = 8 if act == "gelu" else C
+    x = torch.randn(B, C, H, H, generator=g).to(dev)
+    w = (torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).to(dev)
+    wpk, wsc = ops.pack_conv_weight_f16s(w)
+    _, ws = ops.conv2d_f16s(x, wpk, wsc, None, C, 3, 3, 1, (1, 1), stats_groups=groups)
+    coef = ops.group_norm_coef(ws.clone(), None, None, groups, B, C, H * H)
+    for _ in range(5):
+        ops.conv2d_f16s_prenorm(x, coef, -1.0 if act == "gelu" else 0.01, wpk, wsc, None, C, stats_groups=groups)
 torch.cuda.synchronize()
