@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""bench.py -- cine frames/s (seg + flow) at 256x256 on N MI355X, with the roofline of the dominant kernel and the
-CPU baseline timed beside it.
+"""bench.py -- cine frames/s (seg + flow) at 256x256 on N MI355X, with the roofline of the dominant kernel, the
+correlation kernels' HBM rooflines and the CPU baseline timed beside it.
 
 A "step" is one pass of the hot path over one batch of synthetic cine slices (BASELINE.json config 4):
   B slices x T=30 frames x 256x256  ->  2-D U-Net segmentation of every frame (4-flip TTA)  +  SegFlowGaussian
@@ -8,14 +8,25 @@ A "step" is one pass of the hot path over one batch of synthetic cine slices (BA
   reference's two ED-anchored half sequences  +  ED-label propagation by the fused one-hot warp.
 Inputs and weights are resident in HBM before the timed region; outputs stay in HBM.  frames/s = N*B*T*K / time.
 
+BASELINE config 3 (RAFT: all-pairs correlation pyramid + 12 update iterations per 256x256 frame pair,
+SegFlowGaussian.py:875-969) is measured by the same command as a nested object `config3_raft` of the ONE JSON line
+(`--variant raft` makes it the headline of the line instead; `--no-raft` skips it).
+
 Usage (driver contract):  python bench.py --gpus N --steps K --warmup W
-For N>1 it is launched under torch.distributed.run, one rank per GPU; ranks run independent patient shards (weak
-scaling, no data-path collective); rank 0 broadcasts the weights once over RCCL and prints ONE JSON line.
+  * N > 1 without WORLD_SIZE in the environment: this process starts N ranks of itself (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, one per GPU) BEFORE anything touches the GPU, relays rank 0's JSON line and exits non-zero if a rank
+    fails.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` it is one of the ranks.
+  * ranks run independent patient shards (weak scaling, no data-path collective); rank 0 "reads the checkpoint" and
+    broadcasts the weights once over RCCL; the step time is the MAX over ranks; rank 0 prints ONE JSON line.
+  * --dry-run: the same launch / rendezvous / broadcast / barrier / max-over-ranks path on gloo + CPU tensors with the
+    GPU work replaced by a sleep (tests/test_distributed_cpu.py runs it at N = 2 in the build container).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,55 +43,63 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA (neve
 
 
 def synthetic_cine(B, T, S, seed):
-    """bright annulus of radius 40+6cos(2 pi t/T), blobs, noise sigma 0.05, z-scored."""
+    """bright annulus of radius 40+6cos(2 pi t/T), six blobs, noise sigma 0.05, z-scored per
+    frame.  Vectorised over (T, B): a fraction of a second for 32 x 30 frames (the per-frame Python loop took 50 s)."""
     g = torch.Generator().manual_seed(seed)
-    yy, xx = torch.meshgrid(torch.arange(S, dtype=torch.float32), torch.arange(S, dtype=torch.float32), indexing="ij")
-    out = torch.empty(T, B, 1, S, S)
-    for b in range(B):
-        cy, cx = S / 2 + 6 * torch.randn(1, generator=g).item(), S / 2 + 6 * torch.randn(1, generator=g).item()
-        blobs = [(S * torch.rand(1, generator=g).item(), S * torch.rand(1, generator=g).item(), 6 + 10 * torch.rand(1, generator=g).item())
-                 for _ in range(6)]
-        for t in range(T):
-            r = torch.sqrt((yy - cy) ** 2 + (xx - cx) ** 2)
-            rad = 40 + 6 * np.cos(2 * np.pi * t / T)
-            img = torch.exp(-((r - rad) / 5.0) ** 2)
-            for (by, bx, bs) in blobs:
-                img = img + 0.5 * torch.exp(-((yy - by) ** 2 + (xx - bx) ** 2) / (2 * bs * bs))
-            img = img + 0.05 * torch.randn(S, S, generator=g)
-            out[t, b, 0] = (img - img.mean()) / img.std(unbiased=False)
-    return out
+    ax = torch.arange(S, dtype=torch.float32)
+    yy, xx = ax.view(1, 1, S, 1), ax.view(1, 1, 1, S)
+    c = S / 2 + 6 * torch.randn(2, B, generator=g)
+    blob = torch.rand(B, 6, 3, generator=g)
+    by, bx, bs = S * blob[..., 0], S * blob[..., 1], 6 + 10 * blob[..., 2]
+    r = torch.sqrt((yy - c[0].view(1, B, 1, 1)) ** 2 + (xx - c[1].view(1, B, 1, 1)) ** 2)         # [1,B,S,S]
+    rad = (40 + 6 * torch.cos(2 * np.pi * torch.arange(T, dtype=torch.float32) / T)).view(T, 1, 1, 1)
+    img = torch.exp(-((r - rad) / 5.0) ** 2)                                                     # [T,B,S,S]
+    blobs = torch.zeros(1, B, S, S)
+    for k in range(6):
+        blobs += 0.5 * torch.exp(-((yy - by[:, k].view(1, B, 1, 1)) ** 2 + (xx - bx[:, k].view(1, B, 1, 1)) ** 2)
+                                 / (2 * bs[:, k].view(1, B, 1, 1) ** 2))
+    img = img + blobs + 0.05 * torch.randn(T, B, S, S, generator=g)
+    img = (img - img.mean(dim=(2, 3), keepdim=True)) / img.std(dim=(2, 3), unbiased=False, keepdim=True)
+    return img.view(T, B, 1, S, S).contiguous()
 
 
-def build_nets(dev, variant, seed, world, rank):
+def ring_labels(B, S):
+    yy, xx = np.mgrid[:S, :S]
+    rad = np.sqrt((yy - S / 2) ** 2 + (xx - S / 2) ** 2)
+    lab = np.zeros((S, S), np.uint8)
+    for k, r in enumerate((52, 44, 36), start=1):
+        lab[rad < r] = k
+    return torch.from_numpy(lab)[None].repeat(B, 1, 1).contiguous()
+
+
+def flow_net_kwargs(variant):
+    if variant == "raft":      # SegFlowGaussian.py:875-969 with raft_config.yaml:41 raft_iters 12
+        return dict(image_size=256, motion_appearance=False, dim_feedforward=2048, raft=True, raft_iters=12)
+    ma = variant == "raft_config"
+    return dict(image_size=256, motion_appearance=ma, dim_feedforward=3072 if ma else 2048)
+
+
+def make_nets(variant, with_seg=True):
     from cineflow.models import SegFlowGaussian, Generic_UNet
+    nets = [SegFlowGaussian(**flow_net_kwargs(variant))]
+    if with_seg:
+        nets.append(Generic_UNet(1, 32, 4, 6))
+    return nets
+
+
+def load_nets(nets, dev, seed, world, rank):
+    """rank 0 "reads the checkpoint" (the seeded fill); the other ranks receive it as ONE flat broadcast"""
     from cineflow.weights import seeded_state_dict
     from cineflow import parallel
-    ma = variant == "raft_config"
-    fnet = SegFlowGaussian(image_size=256, motion_appearance=ma, dim_feedforward=3072 if ma else 2048)
-    snet = Generic_UNet(1, 32, 4, 6)
-    for net, s in ((fnet, seed), (snet, seed + 1)):
+    for i, net in enumerate(nets):
         shapes = {k: v for k, v in net.state_shapes().items() if not k.endswith("grid")}
-        sd = seeded_state_dict(shapes, s) if rank == 0 else None  # only rank 0 "reads the checkpoint"
+        sd = seeded_state_dict(shapes, seed + i) if rank == 0 else None
         sd = parallel.broadcast_state_dict(sd, shapes, dev) if world > 1 else {k: v.to(dev) for k, v in sd.items()}
-        net.load_state_dict(sd, dev)
-    return fnet, snet
-
-
-def run_step(fnet, snet, frames, ed_labels, seg_chunk):
-    from cineflow.inference import predict_cine_slices
-    return predict_cine_slices(fnet, _ChunkedSeg(snet, seg_chunk), frames, ed_labels)
-
-
-class _ChunkedSeg:
-    """Runs the segmentation U-Net over the T*B frame batch in chunks (bounds activation memory, same numbers)."""
-
-    def __init__(self, net, chunk):
-        self.net, self.chunk, self.num_classes = net, chunk, net.num_classes
-
-    def __call__(self, x):
-        if x.shape[0] <= self.chunk:
-            return self.net(x)
-        return torch.cat([self.net(x[i:i + self.chunk]) for i in range(0, x.shape[0], self.chunk)], 0)
+        if dev.type == "cuda":
+            net.load_state_dict(sd, dev)
+        else:
+            net._dry_checksum = float(sum(float(v.double().sum()) for v in sd.values()))
+    return nets
 
 
 def cpu_baseline(variant, seed, T_sample):
@@ -90,12 +109,18 @@ def cpu_baseline(variant, seed, T_sample):
     from cineflow.weights import fill_module_
     from cineflow.inference import chunk_orders
     from oracle import ops as OO
-    ma = variant == "raft_config"
     torch.set_num_threads(host_threads())
-    fnet = fill_module_(OM.SegFlowGaussian(image_size=256, motion_appearance=ma, dim_feedforward=3072 if ma else 2048), seed)
-    snet = fill_module_(OM.GenericUNet2D(1, 32, 4, 6), seed + 1)
+    fnet = fill_module_(OM.SegFlowGaussian(**flow_net_kwargs(variant)), seed)
     frames = synthetic_cine(1, T_sample, 256, 1234)
     with torch.no_grad():
+        if variant == "raft":
+            fnet(frames[:2])  # warm-up
+            t0 = time.perf_counter()
+            fnet(frames[:2])
+            dt = time.perf_counter() - t0
+            return {"value": 1.0 / dt, "unit": "frame pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                    "sample": "1 frame pair x 12 RAFT iterations (oracle/ CPU PyTorch fp32), %.1f s" % dt}
+        snet = fill_module_(OM.GenericUNet2D(1, 32, 4, 6), seed + 1)
         fnet(frames[:2])  # warm-up (thread pools, oneDNN primitives)
         t0 = time.perf_counter()
         probs = OM.mirror_and_predict_2d(snet, frames.reshape(T_sample, 1, 256, 256))
@@ -127,6 +152,195 @@ def host_threads():
     return max(1, min(n, 16))  # a 1-GPU box gives this process a 16-core share
 
 
+# --------------------------------------------------------------------------------------------------- self-launch
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start n ranks of this script (one per GPU), relay rank 0's stdout (the JSON line) and return the worst exit code.
+    Runs before this process has made any GPU call: the children are fresh processes, nothing is re-exec'd."""
+    import threading
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    pending = set(range(n))
+    try:
+        while pending:
+            time.sleep(0.2)
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    log("rank %d exited with code %d: stopping the other ranks" % (r, code))
+                    for q in pending:
+                        procs[q].terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    reader.join(timeout=10)
+    # only the JSON line goes to stdout; anything else rank 0 printed there (gloo / RCCL banners) is passed on through stderr
+    for ln in b"".join(o for o in out0 if o).decode(errors="replace").splitlines():
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
+    sys.stdout.flush()
+    return rc
+
+
+# --------------------------------------------------------------------------------------------------- measurement
+def read_profile(h, kid):
+    from cineflow import _lib
+    ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+    _lib.check(h.cf_profile_read(kid, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n)), "cf_profile_read")
+    return ms.value, work.value, n.value
+
+
+def hbm_roofline(name, rec):
+    ms, byts, n = rec
+    if not n:
+        return None
+    ach = byts / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": None, "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2)}
+
+
+def conv_roofline(h, dt):
+    """roofline of the dominant convolution kernel from the per-launch event pairs recorded during the timed steps"""
+    conv = [read_profile(h, k) for k in (0, 1, 2, 6)]
+    dom = max(range(4), key=lambda i: conv[i][0])
+    ms, flops, n = conv[dom]
+    if not n:
+        return None
+    ach = flops / (ms * 1e-3) / 1e12
+    if dom == 3:
+        # the f16 hi/lo-split kernel issues 3 f16 MFMAs per algorithmic MAC: priced against the dense f16 MFMA peak,
+        # its ceiling is 1/3; `mfma_issue_frac` is the fraction of the f16 MFMA peak the issued MFMAs reach
+        return {"bound": "mfma", "kernel": "conv_f16s_kernel (f16 MFMA, 3-term hi/lo split, fp32 accumulate)", "achieved": round(ach, 3),
+                "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4),
+                "mfma_issue_frac": round(3 * ach / MFMA_F16_PEAK_TFLOPS, 4), "vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 3),
+                "traffic": None, "traffic_note": "PMC passes are separate runs: profiles/r0*_pmc_hbm_traffic.md (1.00x algorithmic)",
+                "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "share_of_step_time": round(ms * 1e-3 / dt, 3)}
+    return {"bound": "mfma", "kernel": "conv_igemm_f32_kernel<%d,2>" % (1, 2, 4)[dom], "achieved": round(ach, 3),
+            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+            "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "share_of_step_time": round(ms * 1e-3 / dt, 3)}
+
+
+def timed(fn, steps, warmup, h, dev, what):
+    """W untimed steps, then exactly K steps between barrier + synchronize pairs; returns the MAX over ranks"""
+    from cineflow import parallel, _lib
+    for _ in range(warmup):
+        fn()
+        torch.cuda.synchronize()
+        log("%s: warm-up step done" % what)
+    _lib.check(h.cf_profile_enable(60000), "cf_profile_enable")
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    del out
+    dt = parallel.max_over_ranks(dt, dev)
+    log("%s: %d steps in %.3f s" % (what, steps, dt))
+    return dt
+
+
+def bench_joint(args, dev, h, world, rank):
+    """BASELINE config 4 (the headline metric)"""
+    from cineflow.inference import predict_cine_slices
+    B, T, S = args.slices, args.frames, 256
+    fnet, snet = load_nets(make_nets(args.variant), dev, 1234, world, rank)
+    # patient i of the global list is seeded 1234+i and handled by rank i % world (SURVEY.md section 8e)
+    frames = synthetic_cine(B, T, S, 1234 + rank).to(dev)
+    ed_labels = ring_labels(B, S).to(dev)
+    log("joint: weights + inputs resident (rank %d/%d, B=%d, T=%d)" % (rank, world, B, T))
+    dt = timed(lambda: predict_cine_slices(fnet, snet, frames, ed_labels), args.steps, args.warmup, h, dev, "joint")
+    roofline = conv_roofline(h, dt)
+    corr = [read_profile(h, k) for k in (3, 4, 5)]
+    tot = tuple(sum(c[i] for c in corr) for i in range(3))
+    roofline_corr = hbm_roofline("corr_volume_p7_kernel<1|2|4> (persistent)", tot)
+    if roofline_corr:
+        roofline_corr["per_level"] = {"s%d" % s: {"GB/s": round(c[1] / (c[0] * 1e-3) / 1e9, 1), "avg_launch_us": round(c[0] * 1e3 / c[2], 2)}
+                                      for s, c in zip((1, 2, 4), corr) if c[2]}
+    h.cf_profile_enable(0)
+    frames_total = world * B * T * args.steps
+    return {
+        "metric": "cine frames/sec (seg+flow) at 256x256",
+        "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 MFMA hi/lo split, f32 accumulate (f32-class)" if args.conv_mode == "f16s" else "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 4: joint seg+flow over 256x256x%d cine slices; Generic_UNet(32 base, 6 pools) 4-flip TTA on "
+                               "every frame + SegFlowGaussian(%s.yaml) two-chunk ED-anchored recurrence + fused label warp" % (T, args.variant),
+                   "slices_per_step_per_gpu": B, "frames_per_slice": T, "image": "256x256", "sharding": "patients, rank = part_id"},
+        "roofline": roofline, "roofline_corr": roofline_corr,
+    }
+
+
+def bench_raft(args, dev, h, world, rank, steps, warmup):
+    """BASELINE config 3: RAFT flow, 12 update iterations per 256x256 frame pair (fmaps [B,256,32,32]); a step = B pairs"""
+    B, S = args.pairs, 256
+    (fnet,) = load_nets(make_nets("raft", with_seg=False), dev, 1234, world, rank)
+    frames = synthetic_cine(B, 2, S, 4321 + rank).to(dev)
+    log("raft: weights + inputs resident (rank %d/%d, B=%d pairs)" % (rank, world, B))
+    dt = timed(lambda: fnet(frames)["backward_flow"], steps, warmup, h, dev, "raft")
+    roofline = conv_roofline(h, dt)
+    allp, look, up = (read_profile(h, k) for k in (7, 8, 9))
+    h.cf_profile_enable(0)
+    pairs = world * B * steps
+    return {
+        "metric": "RAFT frame pairs/sec (12 update iterations) at 256x256", "value": round(pairs / dt, 2), "unit": "frame pairs/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 2), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f16 MFMA hi/lo split, f32 accumulate (f32-class)" if args.conv_mode == "f16s" else "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE config 3: SegFlowGaussian(raft=True, raft_iters=12) on 256x256 frame pairs: two encoders, all-pairs "
+                               "correlation pyramid (fmaps [B,256,32,32], 4 levels), 12 x (lookup r=4 -> motion encoder -> SepConvGRU -> flow / mask "
+                               "heads -> convex upsampling), memory-encoder refresh", "pairs_per_step_per_gpu": B, "image": "256x256"},
+        "roofline": roofline,
+        "roofline_allpairs": hbm_roofline("all-pairs volume (conv_igemm_f32 with per-sample weights) + 3 pyramid poolings; 7.67 MB / pair", allp),
+        "roofline_lookup": hbm_roofline("corr_lookup_kernel (324 channels written once per iteration)", look),
+        "roofline_upsample": hbm_roofline("convex_upsample_kernel (576-channel mask read once per iteration)", up),
+    }
+
+
+def dry_run(args, world, rank):
+    """gloo + CPU tensors: launch, rendezvous, flat weight broadcast, shard seeding, barrier and max-over-ranks exactly as in
+    the measured path; the GPU step is a sleep.  No libcineflow_hip.so call (there is no GPU to make one on)."""
+    from cineflow import parallel
+    dev = torch.device("cpu")
+    nets = load_nets(make_nets(args.variant, with_seg=args.variant != "raft"), dev, 1234, world, rank)
+    sums = [n._dry_checksum for n in nets]
+    frames = synthetic_cine(2, 4, 64, 1234 + rank)
+    parallel.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (1 + rank))
+    parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    same = all(abs(parallel.max_over_ranks(s, dev) + parallel.max_over_ranks(-s, dev)) < 1e-9 for s in sums)
+    total = parallel.sum_over_ranks(float(frames.numel()), dev)
+    if rank == 0:
+        print(json.dumps({"metric": "cine frames/sec (seg+flow) at 256x256", "value": None, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none (dry run)", "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "dry run of the multi-rank path (gloo, CPU tensors, no GPU work)", "variant": args.variant},
+                          "weights_identical_on_all_ranks": bool(same), "ranks_reporting": int(round(total / frames.numel()))}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,16 +348,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slices", type=int, default=32, help="cine slices per step and per GPU (B)")
     ap.add_argument("--frames", type=int, default=30, help="frames per cine slice (T)")
-    ap.add_argument("--variant", default="video", choices=["video", "raft_config"])
-    ap.add_argument("--seg-chunk", type=int, default=240, help="frames per segmentation U-Net call (240 x 32 ch x 256^2 fp32 stays under the 2 GiB buffer-offset limit of the f16 conv kernel)")
+    ap.add_argument("--pairs", type=int, default=64, help="frame pairs per RAFT step and per GPU")
+    ap.add_argument("--variant", default="video", choices=["video", "raft_config", "raft"],
+                    help="video / raft_config: BASELINE config 4 with that flow dispatch; raft: BASELINE config 3 as the headline line")
+    ap.add_argument("--no-raft", action="store_true", help="skip the nested BASELINE config 3 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", default="f16s", choices=["f16s", "f32"], help="f16s: f16-MFMA hi/lo split (default); f32: exact fp32 MFMA")
     ap.add_argument("--cpu-frames", type=int, default=5)
+    ap.add_argument("--dry-run", action="store_true", help="exercise the multi-rank path on gloo / CPU tensors without GPU work")
     args = ap.parse_args()
 
-    from cineflow import parallel, _lib
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))           # before any GPU call in this process
+
+    from cineflow import parallel
+    if args.dry_run:
+        rank, world, _ = parallel.init_from_env(backend="gloo")
+        assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
+        dry_run(args, world, rank)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    from cineflow import _lib
     rank, world, local_rank = parallel.init_from_env()
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs a GPU (cineflow has no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -151,85 +380,14 @@ def main():
     from cineflow import ops as _ops
     _ops.set_conv_mode(args.conv_mode)
 
-    B, T, S = args.slices, args.frames, 256
-    fnet, snet = build_nets(dev, args.variant, 1234, world, rank)
-    # patient i of the global list is seeded 1234+i and handled by rank i % world
-    frames = synthetic_cine(B, T, S, 1234 + rank).to(dev)
-    yy, xx = np.mgrid[:S, :S]
-    rad = np.sqrt((yy - S / 2) ** 2 + (xx - S / 2) ** 2)
-    lab = np.zeros((S, S), np.uint8)
-    for k, r in enumerate((52, 44, 36), start=1):
-        lab[rad < r] = k
-    ed_labels = torch.from_numpy(lab)[None].repeat(B, 1, 1).contiguous().to(dev)
-
-    log("weights + inputs resident (rank %d/%d, B=%d, T=%d)" % (rank, world, B, T))
-    for _ in range(args.warmup):
-        run_step(fnet, snet, frames, ed_labels, args.seg_chunk)
-        torch.cuda.synchronize()
-        log("warm-up step done")
-
-    _lib.check(h.cf_profile_enable(60000), "cf_profile_enable")
-    parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = run_step(fnet, snet, frames, ed_labels, args.seg_chunk)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    dt = time.perf_counter() - t0
-    dt = parallel.max_over_ranks(dt, dev)
-    log("timed region: %d steps in %.3f s" % (args.steps, dt))
-
-    # ---- roofline of the dominant kernel (conv_igemm, MFMA-bound) and of the correlation kernel (HBM-bound), from the
-    # per-launch event pairs recorded during the timed steps
-    def read(kid):
-        ms, work, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
-        _lib.check(h.cf_profile_read(kid, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n)), "cf_profile_read")
-        return ms.value, work.value, n.value
-
-    conv = [read(k) for k in (0, 1, 2, 6)]
-    corr = [read(k) for k in (3, 4, 5)]
-    h.cf_profile_enable(0)
-    dom = max(range(4), key=lambda i: conv[i][0])
-    ms, flops, n = conv[dom]
-    roofline = None
-    if n:
-        ach = flops / (ms * 1e-3) / 1e12
-        if dom == 3:
-            # the f16 hi/lo-split kernel issues 3 f16 MFMAs per algorithmic MAC: priced against the dense f16 MFMA peak,
-            # its ceiling is 1/3; `mfma_issue_frac` is the fraction of the f16 MFMA peak the issued MFMAs reach
-            roofline = {"bound": "mfma", "kernel": "conv_f16s_kernel (f16 MFMA, 3-term hi/lo split, fp32 accumulate)", "achieved": round(ach, 3),
-                        "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4),
-                        "mfma_issue_frac": round(3 * ach / MFMA_F16_PEAK_TFLOPS, 4), "vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 3),
-                        "traffic": None, "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "share_of_step_time": round(ms * 1e-3 / dt, 3)}
-        else:
-            roofline = {"bound": "mfma", "kernel": "conv_igemm_f32_kernel<%d,2>" % (1, 2, 4)[dom], "achieved": round(ach, 3),
-                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
-                        "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "share_of_step_time": round(ms * 1e-3 / dt, 3)}
-    cms = sum(c[0] for c in corr)
-    cbytes = sum(c[1] for c in corr)
-    cn = sum(c[2] for c in corr)
-    roofline_corr = None
-    if cn:
-        ach = cbytes / (cms * 1e-3) / 1e9
-        roofline_corr = {"bound": "hbm", "kernel": "corr_volume_p7_kernel<1|2|4> (persistent)", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": cn,
-                         "avg_launch_us": round(cms * 1e3 / cn, 2),
-                         "per_level": {"s%d" % s: {"GB/s": round(c[1] / (c[0] * 1e-3) / 1e9, 1), "avg_launch_us": round(c[0] * 1e3 / c[2], 2)}
-                                       for s, c in zip((1, 2, 4), corr) if c[2]}}
-
+    if args.variant == "raft":
+        line = bench_raft(args, dev, h, world, rank, args.steps, args.warmup)
+    else:
+        line = bench_joint(args, dev, h, world, rank)
+        if not args.no_raft:
+            torch.cuda.empty_cache()
+            line["config3_raft"] = bench_raft(args, dev, h, world, rank, max(1, args.steps), 1)
     if rank == 0:
-        frames_total = world * B * T * args.steps
-        line = {
-            "metric": "cine frames/sec (seg+flow) at 256x256",
-            "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 MFMA hi/lo split, f32 accumulate (f32-class)" if args.conv_mode == "f16s" else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 4: joint seg+flow over 256x256x%d cine slices; Generic_UNet(32 base, 6 pools) 4-flip TTA on "
-                                   "every frame + SegFlowGaussian(%s.yaml) two-chunk ED-anchored recurrence + fused label warp" % (T, args.variant),
-                       "slices_per_step_per_gpu": B, "frames_per_slice": T, "image": "256x256", "sharding": "patients, rank = part_id"},
-            "roofline": roofline, "roofline_corr": roofline_corr,
-        }
         if world == 1 and not args.no_cpu_baseline:
             log("timing the CPU baseline (oracle, %d threads) ..." % host_threads())
             line["cpu_baseline"] = cpu_baseline(args.variant, 1234, args.cpu_frames)

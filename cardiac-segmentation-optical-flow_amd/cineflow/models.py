@@ -76,19 +76,27 @@ class SepConvGRU(Module):
         self.convr2 = Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
         self.convq2 = Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
 
-    def _fused(self, cr, cz):
+    def _fused(self, cr, cz, c1):
+        """[r | z] gate convolution of one pass as ONE layer (weights concatenated on Cout): packed for the f16-split kernel
+        (split-aware for cat[h, x]) and, for CONV_MODE 'f32', as the fp32 kernel's transposed matrix."""
         if not hasattr(cr, "_wt"):
             raise RuntimeError("SepConvGRU weights not loaded")
-        return torch.cat([cr._wt, cz._wt], dim=1).contiguous(), torch.cat([cr._p["bias"], cz._p["bias"]]).contiguous()
+        w = torch.cat([cr._p["weight"], cz._p["weight"]], dim=0).contiguous()
+        c1k = c1 if c1 % ops.f16s_chunk(*cz.ks) else None
+        return {"wt": ops.prep_conv_weight(w), "b": torch.cat([cr._p["bias"], cz._p["bias"]]).contiguous(),
+                "pk": ops.pack_conv_weight_f16s(w, c1=c1k) if cz._f16s else None}
 
     def forward(self, h, x):
         H = self.hidden_dim
         for (cz, cr, cq) in ((self.convz1, self.convr1, self.convq1), (self.convz2, self.convr2, self.convq2)):
-            key = "_rz_%d" % id(cz)
+            key = "_rz_%d_%d" % (id(cz), h.shape[1])
             if key not in self.__dict__:
-                self.__dict__[key] = self._fused(cr, cz)
-            wt, b = self.__dict__[key]
-            gates = ops.conv2d(h, wt, b, 2 * H, cz.ks[0], cz.ks[1], 1, cz.pad, x2=x, act="sigmoid")  # [r | z]
+                self.__dict__[key] = self._fused(cr, cz, h.shape[1])
+            f = self.__dict__[key]
+            if f["pk"] is not None and ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(h, x, cz.ks[0]):
+                gates = ops.conv2d_f16s(h, f["pk"][0], f["pk"][1], f["b"], 2 * H, cz.ks[0], cz.ks[1], 1, cz.pad, x2=x, act="sigmoid")  # [r | z]
+            else:
+                gates = ops.conv2d(h, f["wt"], f["b"], 2 * H, cz.ks[0], cz.ks[1], 1, cz.pad, x2=x, act="sigmoid")
             rh = ops.gru_reset_mul(gates, h)
             q = cq(rh, x2=x, act="tanh")
             h = ops.gru_blend(gates, h, q)
@@ -122,10 +130,13 @@ class BasicUpdateBlock(Module):
         net = self.gru(net, inp_motion)
         delta = self.flow_head(net)
         m = self.mask[0](net, act="relu")
-        wt, b = self.mask[2]._wt, self.mask[2]._p["bias"]
+        c2 = self.mask[2]
         if "_mask_scaled" not in self.__dict__:
-            self.__dict__["_mask_scaled"] = (0.25 * b).contiguous()  # 0.25 * (W x + b) = alpha * conv + 0.25 b
-        mask = ops.conv2d(m, wt, self.__dict__["_mask_scaled"], 576, 1, 1, alpha=0.25)
+            self.__dict__["_mask_scaled"] = (0.25 * c2._p["bias"]).contiguous()  # 0.25 * (W x + b) = alpha * conv + 0.25 b
+        if c2._f16s and ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(m, None, 1):
+            mask = ops.conv2d_f16s(m, c2._wpk, c2._ws, self.__dict__["_mask_scaled"], 576, 1, 1, alpha=0.25)
+        else:
+            mask = ops.conv2d(m, c2._wt, self.__dict__["_mask_scaled"], 576, 1, 1, alpha=0.25)
         return net, mask, delta
 
 

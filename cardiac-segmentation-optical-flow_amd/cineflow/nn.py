@@ -92,6 +92,16 @@ class Conv2d(Module):
             self._f16s = ops.f16s_supported(self.ks[0], self.ks[1], self.stride, self.pad)
             if self._f16s:
                 self._wpk, self._ws = ops.pack_conv_weight_f16s(self._p["weight"])
+                self._wpk_split = {}
+
+    def _packed(self, x, x2):
+        """packed weights for this call's channel split (cat[x, x2] with x.shape[1] not a chunk multiple: packed once per split)"""
+        c1 = x.shape[1]
+        if x2 is None or c1 % ops.f16s_chunk(*self.ks) == 0:
+            return self._wpk, self._ws
+        if c1 not in self._wpk_split:
+            self._wpk_split[c1] = ops.pack_conv_weight_f16s(self._p["weight"], c1=c1)
+        return self._wpk_split[c1]
 
     def forward(self, x, x2=None, act=None, res=None, out=None, out_coff=0, stats_groups=None):
         """stats_groups=G: returns (out, ws) with the GroupNorm statistics of `out` when the f16 kernel can fuse them, else (out, None)."""
@@ -99,7 +109,8 @@ class Conv2d(Module):
                 and ops.small_cin_supported(self.cin, self.ks[0], self.ks[1], self.stride, self.pad, stats_groups)):
             return ops.conv2d_small_cin(x, self._p["weight"], self._p.get("bias"), stats_groups)      # the stems: direct fp32, HBM-bound
         if self._f16s and ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, x2, self.ks[0]):
-            return ops.conv2d_f16s(x, self._wpk, self._ws, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad,
+            wpk, wsc = self._packed(x, x2)
+            return ops.conv2d_f16s(x, wpk, wsc, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad,
                                    x2=x2, act=act, res=res, out=out, out_coff=out_coff, stats_groups=stats_groups)
         if stats_groups:
             return ops.conv2d(x, self._wt, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad, x2=x2, act=act,
@@ -203,12 +214,16 @@ class Conv3d(Module):
         self._taps = []
         for dz in range(self.ks[0]):
             w2 = self._p["weight"][:, :, dz].contiguous()
-            self._taps.append((ops.prep_conv_weight(w2), ops.pack_conv_weight_f16s(w2) if self._f16s else None))
+            self._taps.append((ops.prep_conv_weight(w2), {None: ops.pack_conv_weight_f16s(w2)} if self._f16s else None, w2))
 
     def _conv2d(self, dz, x, x2, bias, res, out):
         k, st, pad = self.ks[1], self.stride[1], (self.ks[1] // 2, self.ks[1] // 2)
-        wt, pk = self._taps[dz]
+        wt, pks, w2 = self._taps[dz]
         if self._f16s and ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, x2, k):
+            key = x.shape[1] if (x2 is not None and x.shape[1] % ops.f16s_chunk(k, k)) else None
+            if key not in pks:
+                pks[key] = ops.pack_conv_weight_f16s(w2, c1=key)      # split-aware packing, once per channel split
+            pk = pks[key]
             return ops.conv2d_f16s(x, pk[0], pk[1], bias, self.cout, k, k, st, pad, x2=x2, res=res, out=out)
         return ops.conv2d(x, wt, bias, self.cout, k, k, st, pad, x2=x2, res=res, out=out)
 

@@ -159,38 +159,56 @@ def set_conv_mode(mode):
 
 
 def f16s_supported(kh, kw, stride, pad):
-    return stride in (1, 2) and ((kh == 3 and kw == 3 and tuple(pad) == (1, 1)) or (kh == 1 and kw == 1 and tuple(pad) == (0, 0)))
+    """kernel shapes of conv_f16s.hip: 3x3 pad 1 and 1x1 pad 0 at stride 1 / 2; the separable 1x5 pad (0,2) / 5x1 pad (2,0) of RAFT's
+    SepConvGRU at stride 1.  (The 7x7 convolution of the 2-channel flow in RAFT's motion encoder stays on the exact fp32 kernel by
+    design: padding 2 channels to a 16-channel chunk would do 8x the work.)"""
+    pad = tuple(pad)
+    if stride in (1, 2) and ((kh, kw, pad) == (3, 3, (1, 1)) or (kh, kw, pad) == (1, 1, (0, 0))):
+        return True
+    return stride == 1 and ((kh, kw, pad) == (1, 5, (0, 2)) or (kh, kw, pad) == (5, 1, (2, 0)))
 
 
-def f16s_dynamic_ok(x1, x2, kh):
-    """Run-time limits of conv_f16s.hip: a channel chunk (16 for 3x3, 32 for 1x1) must not straddle cat[x1, x2], and the
-    inputs are addressed with 32-bit buffer offsets (< 2 GiB each).  Otherwise the caller uses the exact fp32 kernel."""
-    ck = 16 if kh == 3 else 32
-    if x2 is not None and x1.shape[1] % ck:
-        return False
-    if x1.numel() * 4 >= 2 ** 31 or (x2 is not None and x2.numel() * 4 >= 2 ** 31):
-        return False
-    return True
+def f16s_chunk(kh, kw):
+    """channels per LDS chunk of the kernel shape (16 for 3x3, 32 otherwise)"""
+    return 16 if (kh, kw) == (3, 3) else 32
 
 
-def pack_conv_weight_f16s(w):
-    """torch conv weight [Cout,Cin,KH,KW] (KH*KW in {1,9}) -> (packed fp16 tensor, scale exponent s).
+def f16s_dynamic_ok(x1, x2, kh, kw=None):
+    """Run-time limit of conv_f16s.hip: one sample of each input below 2 GiB (32-bit buffer offsets; larger BATCHES are split inside
+    the library).  A cat[x1, x2] whose split is not a chunk multiple is handled by split-aware weight packing
+    (pack_conv_weight_f16s(w, c1=...)), not by another kernel."""
+    per = lambda t: 0 if t is None else (t.numel() // t.shape[0]) * 4
+    return per(x1) < 2 ** 31 and per(x2) < 2 ** 31
+
+
+def pack_conv_weight_f16s(w, c1=None):
+    """torch conv weight [Cout,Cin,KH,KW] (3x3, 1x1, 1x5, 5x1) -> (packed fp16 tensor, scale exponent s).
 
     Fragment order [m-tile][chunk][tap][kstep][part hi/lo][lane = h*32 + r][j]: value = 2^s * W[mt*32 + r][chunk*CK + kstep*16 + 8h + j][tap],
-    CK = 16 (3x3) or 32 (1x1); m-tiles padded to an even count when Cout > 32, channels padded to CK; the power of two
-    2^s brings max|W| to ~2^10 so that the lo halves stay in fp16's normal range (exact scaling, undone through alpha)."""
+    CK = 16 (3x3) or 32; m-tiles padded to an even count when Cout > 32, channels padded to CK; the power of two
+    2^s brings max|W| to ~2^10 so that the lo halves stay in fp16's normal range (exact scaling, undone through alpha).
+    c1: the input is cat[x1 (c1 channels), x2]: x1's channels are padded to whole chunks (zero weights), x2's follow -- the kernel
+    switches input pointers at a chunk boundary."""
     import math
     cout, cin, kh, kw = w.shape
     ntap = kh * kw
-    ck = 16 if ntap == 9 else 32
+    ck = f16s_chunk(kh, kw)
     ks = ck // 16
     nmt = 1 if cout <= 32 else 2 * ((cout + 63) // 64)
-    nchunk = (cin + ck - 1) // ck
     wmax = float(w.abs().max())
     s = int(math.floor(math.log2(1024.0 / wmax))) if wmax > 0 else 0
     s = max(-24, min(24, s))
-    wp = torch.zeros((nmt * 32, nchunk * ck, ntap), dtype=torch.float32, device=w.device)
-    wp[:cout, :cin] = w.reshape(cout, cin, ntap).to(torch.float32) * (2.0 ** s)
+    ws = w.reshape(cout, cin, ntap).to(torch.float32) * (2.0 ** s)
+    if c1 is not None and 0 < c1 < cin and c1 % ck:
+        c1p = (c1 + ck - 1) // ck * ck
+        nchunk = c1p // ck + (cin - c1 + ck - 1) // ck
+        wp = torch.zeros((nmt * 32, nchunk * ck, ntap), dtype=torch.float32, device=w.device)
+        wp[:cout, :c1] = ws[:, :c1]
+        wp[:cout, c1p:c1p + cin - c1] = ws[:, c1:]
+    else:
+        nchunk = (cin + ck - 1) // ck
+        wp = torch.zeros((nmt * 32, nchunk * ck, ntap), dtype=torch.float32, device=w.device)
+        wp[:cout, :cin] = ws
     hi = wp.half()
     lo = (wp - hi.float()).half()
     x = torch.stack([hi, lo])                                  # [part, co, ci, tap]

@@ -26,6 +26,8 @@ struct ConvParams {
     const float* in_norm = nullptr;
     float in_slope = 1.0f;   // LeakyReLU slope; in_slope < 0 selects GELU (erf form) instead
     int probe = 0;          // 1: run the dispatch and its checks only, launch nothing (capability query)
+    int profile_kid = -1;   // >= 0: time this launch under that profile id with `profile_work` instead of the conv's own id / flops
+    double profile_work = 0.0;
 };
 
 // validates nothing; callers validate.  Returns CF_OK / CF_ERR_LAUNCH.

@@ -167,7 +167,8 @@ static int launch_t(const ConvParams& p, hipStream_t s) {
     long ntiles = (Ntot + 32 * NT * 4 - 1) / (32 * NT * 4);
     dim3 grid((unsigned)ntiles, (unsigned)((p.Cout + 32 * MT - 1) / (32 * MT)));
     const double flops = 2.0 * (double)Ntot * p.Cout * (p.C1 + p.C2) * p.KH * p.KW;
-    launch_profiled(MT == 1 ? PK_CONV_MT1 : (MT == 2 ? PK_CONV_MT2 : PK_CONV_MT4), flops, conv_igemm_f32_kernel<MT, NT>, grid, dim3(256), s, p);
+    if (p.profile_kid >= 0) launch_profiled(p.profile_kid, p.profile_work, conv_igemm_f32_kernel<MT, NT>, grid, dim3(256), s, p);
+    else launch_profiled(MT == 1 ? PK_CONV_MT1 : (MT == 2 ? PK_CONV_MT2 : PK_CONV_MT4), flops, conv_igemm_f32_kernel<MT, NT>, grid, dim3(256), s, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error(std::string("conv launch failed: ") + hipGetErrorString(e));

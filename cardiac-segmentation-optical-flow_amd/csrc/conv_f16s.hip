@@ -43,6 +43,7 @@ struct F16sGeom {
     int ostep;               // patch step between output pixels (stride, or 1 for 1x1 convs)
     int tiles_x, tiles_y, bgroups;
     int nchunk;
+    int c1_pad;              // C1 rounded up to a multiple of CK: chunks below it read x1, the others x2 (the packed weights follow the same split)
     int NQ;                  // vector staging: 16-byte column quads per patch row (0: scalar staging)
     // magic multipliers floor(2^32/d)+1 for the index decodes (exact for n < 2^32/d; d == 1 handled apart): the kernel's setup was
     // ~8k ticks of integer division sequences, a tenth of a 4-chunk workgroup's life
@@ -53,8 +54,10 @@ struct F16sGeom {
 __host__ __device__ inline unsigned f16s_magic(int d) { return d <= 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)d + 1ull); }
 __device__ __forceinline__ int fdiv(int n, int d, unsigned m) { return d <= 1 ? n : (int)__umulhi((unsigned)n, m); }
 
+// No range clamp: an activation beyond fp16's range (|x| >= 65520) becomes hi = inf, lo = NaN and poisons the output loudly, NaN and
+// Inf inputs propagate as they do through an fp32 convolution (a clamp here saturated them silently and cost one VALU per element).
+// Supported activation range: |x| < 65504, stated in include/cineflow.h.
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
-    x = __builtin_amdgcn_fmed3f(x, -60000.f, 60000.f);  // one v_med3_f32: keeps huge inputs finite in fp16
     hi = (_Float16)x;
     lo = (_Float16)(x - (float)hi);
 }
@@ -64,10 +67,10 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 // chunks of loads in flight, always one LDS buffer ahead.  vmcnt retires in issue order, so in the mixed design every
 // wait for a weight fragment also waited for the staging loads issued before it (ablating those loads made the kernel
 // 19-33 % faster); with separate roles nothing in the MFMA waves ever waits for HBM.
-template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE>
-__global__ void __launch_bounds__(64 * NW + 64 * NLW, NLW ? 5 : (NW == 8 ? 2 : ((NTW <= 2 && MAXT <= 3) ? 4 : 2)))
+template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE>
+__global__ void __launch_bounds__(64 * NW + 64 * NLW, NLW ? 5 : (NW == 8 ? 4 : ((NTW <= 2 && MAXT <= 3) ? 4 : 2)))
 conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restrict__ wpk) {
-    constexpr int KW = (KHW == 9) ? 3 : 1;
+    constexpr int KHW = KH * KW;           // taps: 3x3, 1x1, and the separable 1x5 / 5x1 of RAFT's SepConvGRU
     constexpr int KS = CK / 16;            // MFMA k-steps per tap per chunk
     constexpr int REC = CK * 4 + 16;       // bytes per pixel record
     constexpr int NT_WG = NTW * (NW / WM);  // n-tiles per workgroup (NW MFMA waves = WM m-tiles x NW/WM n-tile groups)
@@ -151,8 +154,8 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     // The loaded values stay RAW in registers until the LDS write (nothing consumes a load result early).
     auto issue_loads = [&](int chunk, float (&stg)[MAXT][8]) {
         const int c0 = chunk * CK;
-        const bool in1 = c0 < p.C1;                       // workgroup-uniform
-        const unsigned cb = (unsigned)(in1 ? c0 : c0 - p.C1);
+        const bool in1 = c0 < g.c1_pad;                   // workgroup-uniform; c1_pad = C1 rounded up to whole chunks (split-aware packing)
+        const unsigned cb = (unsigned)(in1 ? c0 : c0 - g.c1_pad);
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             const unsigned v0 = (in1 ? t_o1[t] : t_o2[t]) + (cb + t_g8[t]) * HW4;
@@ -225,8 +228,8 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     }
     auto issue_loads_v = [&](int chunk, f32x4v (&stg)[VT][4]) {
         const int c0 = chunk * CK;
-        const bool in1 = c0 < p.C1;
-        const unsigned cb = (unsigned)(in1 ? c0 : c0 - p.C1);
+        const bool in1 = c0 < g.c1_pad;
+        const unsigned cb = (unsigned)(in1 ? c0 : c0 - g.c1_pad);
 #pragma unroll
         for (int t = 0; t < VT; ++t) {
             const unsigned v0 = (in1 ? v_o1[t] : v_o2[t]) + (cb + v_c4[t]) * HW4;
@@ -373,7 +376,10 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const int toff = ((tap / KW) * g.PWR + (tap % KW == 0 ? 0 : (tap % KW == 1 ? g.kx1 : g.kx2))) * REC;
+            // record offset of tap (ky, kx); stride 2 stores the patch columns de-interleaved (even columns, then odd), so column
+            // 2 * txx + kx sits at txx + (kx >> 1) + (kx & 1) * pwh
+            const int ky = tap / KW, kx = tap % KW;      // compile-time after unrolling
+            const int toff = (ky * g.PWR + (g.pwh ? (kx >> 1) + (kx & 1) * g.pwh : kx)) * REC;
             const f16x8 ah = aH[step % R], al = aL[step % R];
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
@@ -585,40 +591,45 @@ static int f16s_vec() {
     return v;
 }
 
-template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE = 0>
+template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE = 0>
 static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s);
 
-// picks the vector-staging instantiation when the layer qualifies (stride 1, W % 4 == 0, 16-byte aligned inputs, one
-// 4x4 task per staging thread), else the scalar one
-template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW = 0, int NW = 4>
+// picks the vector-staging instantiation when the layer qualifies (stride 1, W % 4 == 0, 16-byte aligned inputs, VT 4x4 tasks per
+// staging thread), else the scalar one.  VT = 1 for the 3x3 shapes; the 1x5 / 5x1 shapes (CK = 32, wider patches) take VT = 2.
+template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW = 0, int NW = 4>
 static int launch_f16s(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s) {
+    constexpr int KHW = KH * KW;
     g.NQ = 0;
-    // (1x1 layers measured 6-17 % slower with it -- their scalar loads are already whole rows -- so 3x3 only)
-    if (NLW == 0 && KHW == 9 && f16s_vec() && p.stride == 1 && (p.W & 3) == 0 && (g.TW & 3) == 0 &&
+    // (1x1 layers measured 6-17 % slower with it -- their scalar loads are already whole rows -- so spatial kernels only)
+    if (NLW == 0 && KHW > 1 && f16s_vec() && p.stride == 1 && (p.W & 3) == 0 && (g.TW & 3) == 0 &&
         ((reinterpret_cast<uintptr_t>(p.x1) | reinterpret_cast<uintptr_t>(p.x2)) & 15) == 0) {
         const int a = (-p.pad_w) & 3;                       // ix_org mod 4 (tile origins are multiples of 4)
         const int nq = ((a + g.PW - 1) >> 2) + 1;
         const int tasks = (CK / 4) * g.NIMG * g.PH * nq;
         g.NQ = nq;
-        if (tasks <= 64 * NW) {
-            // the stride-1 3x3 four-wave shapes are also built with the deferred input normalisation; not the 8-wave shape of the small
-            // maps (< 1024 workgroups): its short workgroups lose more to the table fill + barrier than the apply pass costs
-            // (256 channels at 32x32, B = 32: 192 us vs 120 + 15 us, tools/prenorm_ab.py)
-            if constexpr (MAXT == 2 && KHW == 9 && NLW == 0 && NW == 4) {
-                if (p.in_norm && g.NIMG == 1 && p.C2 == 0 && (reinterpret_cast<uintptr_t>(p.in_norm) & 3) == 0)
-                    return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 1, 1>(p, g, wpk, s);
+        if constexpr (KHW == 9) {
+            if (tasks <= 64 * NW) {
+                // the stride-1 3x3 four-wave shapes are also built with the deferred input normalisation; not the 8-wave shape of the small
+                // maps (< 1024 workgroups): its short workgroups lose more to the table fill + barrier than the apply pass costs
+                // (256 channels at 32x32, B = 32: 192 us vs 120 + 15 us, tools/prenorm_ab.py)
+                if constexpr (MAXT == 2 && NLW == 0 && NW == 4) {
+                    if (p.in_norm && g.NIMG == 1 && p.C2 == 0 && (reinterpret_cast<uintptr_t>(p.in_norm) & 3) == 0)
+                        return launch_f16s_v<KH, KW, CK, WM, NTW, MAXT, NLW, NW, 1, 1>(p, g, wpk, s);
+                }
+                if (p.in_norm) { set_error("conv_f16s: deferred input normalisation is not built for this layer shape"); return CF_ERR_ARG; }
+                return launch_f16s_v<KH, KW, CK, WM, NTW, MAXT, NLW, NW, 1>(p, g, wpk, s);
             }
-            if (p.in_norm) { set_error("conv_f16s: deferred input normalisation is not built for this layer shape"); return CF_ERR_ARG; }
-            return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 1>(p, g, wpk, s);
+            // (two tasks per thread for the (2 TH + 1) x (2 TW + 1) patches of the stride-2 shapes: measured equal or 2 % slower, not built)
+        } else if constexpr (KHW > 1) {
+            if (!p.in_norm && tasks <= 2 * 64 * NW) return launch_f16s_v<KH, KW, CK, WM, NTW, MAXT, NLW, NW, 2>(p, g, wpk, s);
         }
-        // (two tasks per thread for the (2 TH + 1) x (2 TW + 1) patches of the stride-2 shapes: measured equal or 2 % slower, not built)
         g.NQ = 0;
     }
     if (p.in_norm) { set_error("conv_f16s: deferred input normalisation needs the vector staging path (3x3, stride 1, W % 4 == 0)"); return CF_ERR_ARG; }
-    return launch_f16s_v<KHW, CK, WM, NTW, MAXT, NLW, NW, 0>(p, g, wpk, s);
+    return launch_f16s_v<KH, KW, CK, WM, NTW, MAXT, NLW, NW, 0>(p, g, wpk, s);
 }
 
-template <int KHW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE>
+template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE>
 static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s) {
     constexpr int REC = CK * 4 + 16;
     constexpr int NSTAGE = NLW ? 64 * NLW : 64 * NW;
@@ -647,7 +658,7 @@ static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, h
         return CF_ERR_ARG;
     }
     if (p.probe) return CF_OK;
-    auto kern = conv_f16s_kernel<KHW, CK, WM, NTW, MAXT, NLW, NW, VEC, PRE>;
+    auto kern = conv_f16s_kernel<KH, KW, CK, WM, NTW, MAXT, NLW, NW, VEC, PRE>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -669,14 +680,22 @@ static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, h
     return CF_OK;
 }
 
+// kernel shapes of the f16-split kernel: 3x3 pad 1 and 1x1 pad 0 at stride 1 / 2, and the separable 1x5 (pad 0,2) / 5x1 (pad 2,0)
+// convolutions of RAFT's SepConvGRU at stride 1
+static int f16s_kind(const ConvParams& p) {
+    if (p.KH == 3 && p.KW == 3 && p.pad_h == 1 && p.pad_w == 1 && (p.stride == 1 || p.stride == 2)) return 33;
+    if (p.KH == 1 && p.KW == 1 && p.pad_h == 0 && p.pad_w == 0 && (p.stride == 1 || p.stride == 2)) return 11;
+    if (p.KH == 1 && p.KW == 5 && p.pad_h == 0 && p.pad_w == 2 && p.stride == 1) return 15;
+    if (p.KH == 5 && p.KW == 1 && p.pad_h == 2 && p.pad_w == 0 && p.stride == 1) return 51;
+    return 0;
+}
+
+// One sample of each input must stay below 2 GiB (32-bit buffer offsets); larger batches are split by launch_conv_f16s itself.
 bool conv_f16s_supported(const ConvParams& p) {
     if (p.w_bstride) return false;
-    if (!((p.KH == 3 && p.KW == 3 && p.pad_h == 1 && p.pad_w == 1) || (p.KH == 1 && p.KW == 1 && p.pad_h == 0 && p.pad_w == 0))) return false;
-    if (p.stride != 1 && p.stride != 2) return false;
-    const int ck = (p.KH == 3) ? 16 : 32;
-    if (p.C2 > 0 && (p.C1 % ck)) return false;  // a channel chunk must not straddle x1 | x2
+    if (!f16s_kind(p)) return false;
     const long HW = (long)p.H * p.W;
-    if ((long)p.B * p.C1 * HW * 4 >= (1L << 31) || (long)p.B * p.C2 * HW * 4 >= (1L << 31)) return false;  // 32-bit buffer offsets
+    if ((long)p.C1 * HW * 4 >= (1L << 31) || (long)p.C2 * HW * 4 >= (1L << 31)) return false;
     return true;
 }
 
@@ -714,9 +733,10 @@ static int f16s_small_tile() {
 
 static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipStream_t s, bool* one_sample_per_wg);
 
-// Runs the convolution; when p.gn_ws is set the workspace ends up holding the GroupNorm statistics of the output --
-// from the fused epilogue when every workgroup covers a single sample, otherwise from the separate statistics pass.
-int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
+// Runs the convolution on a batch whose inputs fit 32-bit buffer offsets; when p.gn_ws is set the workspace ends up holding the
+// GroupNorm statistics of the output -- from the fused epilogue when every workgroup covers a single sample, otherwise from the
+// separate statistics pass.
+static int launch_conv_f16s_part(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
     if (!p.gn_ws) return launch_conv_f16s_impl(p, wpk, s, nullptr);
     bool fusable = false;
     launch_conv_f16s_impl(p, nullptr, s, &fusable);  // geometry probe only
@@ -737,15 +757,45 @@ int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
     return launch_gn_stats(p.out, p.gn_ws, p.B, cout, p.Ho * up * p.Wo * up, p.gn_groups, s);
 }
 
+// The kernel addresses its inputs with 32-bit buffer offsets (< 2 GiB per descriptor).  A batch whose input tensors are larger is
+// cut into sub-batches HERE (same kernel, same numbers, a few more launches) instead of being handed to another kernel: the batch
+// axis is the outermost one of every operand, so a sub-batch is a pointer offset.
+int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
+    const long HW = (long)p.H * p.W;
+    const long per1 = (long)p.C1 * HW * 4, per2 = (long)p.C2 * HW * 4;
+    const long lim = (1L << 31) - 1;
+    long nb = lim / (per1 > per2 ? per1 : per2);
+    if (nb < 1) { set_error("conv_f16s: one sample of the input exceeds 2 GiB"); return CF_ERR_ARG; }
+    if (p.B <= nb) return launch_conv_f16s_part(p, wpk, s);
+    const int up = p.scatter2x2 ? 2 : 1;
+    const long HoWo = (long)p.Ho * p.Wo;
+    for (long b0 = 0; b0 < p.B; b0 += nb) {
+        ConvParams q = p;
+        q.B = (int)(p.B - b0 < nb ? p.B - b0 : nb);
+        q.x1 = p.x1 + b0 * p.C1 * HW;
+        if (p.x2) q.x2 = p.x2 + b0 * p.C2 * HW;
+        if (p.res) q.res = p.res + b0 * p.Cout * HoWo;
+        q.out = p.out + b0 * p.out_ctotal * HoWo * up * up;
+        if (p.gn_ws) q.gn_ws = p.gn_ws + 2 * b0 * p.gn_groups;
+        if (p.in_norm) q.in_norm = p.in_norm + b0 * 3 * p.C1;
+        int rc = launch_conv_f16s_part(q, wpk, s);
+        if (rc != CF_OK) return rc;
+    }
+    return CF_OK;
+}
+
 static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipStream_t s, bool* one_sample_per_wg) {
-    const bool k3 = p.KH == 3;
+    const int kind = f16s_kind(p);
+    const bool k3 = kind == 33;
+    const bool sep = kind == 15 || kind == 51;           // 1x5 / 5x1
+    const bool spatial = k3 || sep;
     const int CK = k3 ? 16 : 32;
     const bool narrow = p.Cout <= 32;
     const bool small = f16s_small_tile() != 0;
     const bool s2 = k3 && p.stride == 2;
     const bool wide = small && !s2 && f16s_wide() && p.Cout % 128 == 0 && f16s_loader_waves() == 0;
     // n-tiles (of 32 output pixels) per workgroup
-    const int NT_WG = s2 ? ((small && !narrow) ? 2 : 4) : (small ? 4 : 8);
+    const int NT_WG = s2 ? ((small && !narrow) ? 2 : 4) : ((small || sep) ? 4 : 8);
     const int npx = NT_WG * 32;
     F16sGeom g;
     g.TW = p.Wo < 32 ? p.Wo : 32;
@@ -758,11 +808,11 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
         if (g.NIMG > p.B) g.NIMG = p.B;
         if (g.NIMG < 1) g.NIMG = 1;
     }
-    if (k3) {
+    if (spatial) {
         g.pstep = 1;
         g.ostep = p.stride;
-        g.PH = (g.TH - 1) * p.stride + 3;
-        g.PW = (g.TW - 1) * p.stride + 3;
+        g.PH = (g.TH - 1) * p.stride + p.KH;
+        g.PW = (g.TW - 1) * p.stride + p.KW;
     } else {
         g.pstep = p.stride;
         g.ostep = 1;
@@ -771,9 +821,9 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     }
     // keep the staging work within the per-thread task budget of the variant (MAXT x 256 eight-channel tasks)
     {
-        const bool ws = small && f16s_loader_waves() > 0;   // 128 staging threads instead of 256
-        const int maxt = ws ? 4 : (s2 ? ((small && !narrow) ? 3 : 5) : (small ? 2 : 4));
-        const int nstage = ws ? ((s2 && !narrow) ? 192 : 128) : (wide ? 512 : 256);
+        const bool ws = small && f16s_loader_waves() > 0 && !sep;   // 128 staging threads instead of 256
+        const int maxt = sep ? 4 : (ws ? 4 : (s2 ? ((small && !narrow) ? 3 : 5) : (small ? 2 : 4)));
+        const int nstage = ws ? ((s2 && !narrow) ? 192 : 128) : ((wide && !sep) ? 512 : 256);
         while (g.NIMG > 1 && (g.NIMG * g.PH * g.PW * (CK / 8) + nstage - 1) / nstage > maxt) --g.NIMG;
     }
     // Stride 2: output-pixel lanes read every second input column; with plain row-major records (80 B apart) their 160-byte lane
@@ -784,10 +834,18 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     g.tiles_x = (p.Wo + g.TW - 1) / g.TW;
     g.tiles_y = (p.Ho + g.TH - 1) / g.TH;
     g.bgroups = (p.B + g.NIMG - 1) / g.NIMG;
-    g.nchunk = (p.C1 + p.C2 + CK - 1) / CK;
+    // split-aware chunking: x1's channels are padded to whole chunks (the packed weights carry zeros there), then x2's follow
+    g.c1_pad = p.C2 > 0 ? ((p.C1 + CK - 1) / CK) * CK : (1 << 30);
+    g.nchunk = p.C2 > 0 ? g.c1_pad / CK + (p.C2 + CK - 1) / CK : (p.C1 + CK - 1) / CK;
     if (one_sample_per_wg) {  // geometry probe
         *one_sample_per_wg = g.NIMG == 1;
         return CF_OK;
+    }
+    if (sep) {
+        // RAFT's SepConvGRU (384 -> 128 / 256 at 1/8 resolution): CK = 32 (10 k-steps per chunk keep the 2-slot fragment ring static);
+        // 128-pixel tiles; 128-channel workgroups when Cout allows (8 waves: 4 m-tiles x 2 pixel groups), else 64-channel ones
+        if (kind == 15) return (p.Cout % 128 == 0) ? launch_f16s<1, 5, 32, 4, 2, 4, 0, 8>(p, g, wpk, s) : launch_f16s<1, 5, 32, 2, 2, 4>(p, g, wpk, s);
+        return (p.Cout % 128 == 0) ? launch_f16s<5, 1, 32, 4, 2, 4, 0, 8>(p, g, wpk, s) : launch_f16s<5, 1, 32, 2, 2, 4>(p, g, wpk, s);
     }
     if (wide && k3) {
         // Two 128-channel shapes.  Four waves, each ONE m-tile x FOUR pixel tiles: a weight fragment feeds 12 MFMAs instead of 6, which
@@ -797,32 +855,32 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
         const long nwg = (long)g.tiles_x * g.tiles_y * g.bgroups * (p.Cout / 128);
         const int mode = f16s_wide();
         const bool four = mode == 2 || (mode == 1 && nwg >= 1024 && g.NIMG == 1);
-        if (four && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 <= 2) return launch_f16s<9, 16, 4, 4, 2, 0, 4>(p, g, wpk, s);
-        return launch_f16s<9, 16, 4, 2, 2, 0, 8>(p, g, wpk, s);
+        if (four && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 <= 2) return launch_f16s<3, 3, 16, 4, 4, 2, 0, 4>(p, g, wpk, s);
+        return launch_f16s<3, 3, 16, 4, 2, 2, 0, 8>(p, g, wpk, s);
     }
     if (wide) {   // 1x1: same choice between the two 128-channel shapes
         const long nwg = (long)g.tiles_x * g.tiles_y * g.bgroups * (p.Cout / 128);
         static int k1four = -1;
         if (k1four < 0) { const char* e = getenv("CF_F16S_K1FOUR"); k1four = e ? atoi(e) : 1; }
-        if (k1four && nwg >= 1024 && g.NIMG == 1 && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 <= 2) return launch_f16s<1, 32, 4, 4, 2, 0, 4>(p, g, wpk, s);
-        return launch_f16s<1, 32, 4, 2, 2, 0, 8>(p, g, wpk, s);
+        if (k1four && nwg >= 1024 && g.NIMG == 1 && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 <= 2) return launch_f16s<1, 1, 32, 4, 4, 2, 0, 4>(p, g, wpk, s);
+        return launch_f16s<1, 1, 32, 4, 2, 2, 0, 8>(p, g, wpk, s);
     }
     if (small && f16s_loader_waves() > 0) {
-        if (narrow && !s2) return k3 ? launch_f16s<9, 16, 1, 1, 4, 2>(p, g, wpk, s) : launch_f16s<1, 32, 1, 1, 4, 2>(p, g, wpk, s);
-        if (s2 && !narrow) return launch_f16s<9, 16, 2, 1, 4, 3>(p, g, wpk, s);
-        if (!narrow) return k3 ? launch_f16s<9, 16, 2, 2, 4, 2>(p, g, wpk, s) : launch_f16s<1, 32, 2, 2, 4, 2>(p, g, wpk, s);
+        if (narrow && !s2) return k3 ? launch_f16s<3, 3, 16, 1, 1, 4, 2>(p, g, wpk, s) : launch_f16s<1, 1, 32, 1, 1, 4, 2>(p, g, wpk, s);
+        if (s2 && !narrow) return launch_f16s<3, 3, 16, 2, 1, 4, 3>(p, g, wpk, s);
+        if (!narrow) return k3 ? launch_f16s<3, 3, 16, 2, 2, 4, 2>(p, g, wpk, s) : launch_f16s<1, 1, 32, 2, 2, 4, 2>(p, g, wpk, s);
     }
-    if (small && narrow && !s2) return k3 ? launch_f16s<9, 16, 1, 1, 2>(p, g, wpk, s) : launch_f16s<1, 32, 1, 1, 2>(p, g, wpk, s);
+    if (small && narrow && !s2) return k3 ? launch_f16s<3, 3, 16, 1, 1, 2>(p, g, wpk, s) : launch_f16s<1, 1, 32, 1, 1, 2>(p, g, wpk, s);
     // stride 2 with Cout % 128 == 0: four m-tiles x two pixel tiles per wave -- every weight fragment is loaded once per workgroup and
     // feeds 6 MFMAs (the 64-channel shape below: loaded twice, 3 MFMAs each)
-    if (small && s2 && !narrow && p.Cout % 128 == 0 && f16s_wide()) return launch_f16s<9, 16, 4, 2, 3>(p, g, wpk, s);
-    if (small && s2 && !narrow) return launch_f16s<9, 16, 2, 1, 3>(p, g, wpk, s);
-    if (small && !narrow) return k3 ? launch_f16s<9, 16, 2, 2, 2>(p, g, wpk, s) : launch_f16s<1, 32, 2, 2, 2>(p, g, wpk, s);
+    if (small && s2 && !narrow && p.Cout % 128 == 0 && f16s_wide()) return launch_f16s<3, 3, 16, 4, 2, 3>(p, g, wpk, s);
+    if (small && s2 && !narrow) return launch_f16s<3, 3, 16, 2, 1, 3>(p, g, wpk, s);
+    if (small && !narrow) return k3 ? launch_f16s<3, 3, 16, 2, 2, 2>(p, g, wpk, s) : launch_f16s<1, 1, 32, 2, 2, 2>(p, g, wpk, s);
     if (k3) {
-        if (p.stride == 1) return narrow ? launch_f16s<9, 16, 1, 2, 4>(p, g, wpk, s) : launch_f16s<9, 16, 2, 4, 4>(p, g, wpk, s);
-        return narrow ? launch_f16s<9, 16, 1, 1, 5>(p, g, wpk, s) : launch_f16s<9, 16, 2, 2, 5>(p, g, wpk, s);
+        if (p.stride == 1) return narrow ? launch_f16s<3, 3, 16, 1, 2, 4>(p, g, wpk, s) : launch_f16s<3, 3, 16, 2, 4, 4>(p, g, wpk, s);
+        return narrow ? launch_f16s<3, 3, 16, 1, 1, 5>(p, g, wpk, s) : launch_f16s<3, 3, 16, 2, 2, 5>(p, g, wpk, s);
     }
-    return narrow ? launch_f16s<1, 32, 1, 2, 4>(p, g, wpk, s) : launch_f16s<1, 32, 2, 4, 4>(p, g, wpk, s);
+    return narrow ? launch_f16s<1, 1, 32, 1, 2, 4>(p, g, wpk, s) : launch_f16s<1, 1, 32, 2, 4, 4>(p, g, wpk, s);
 }
 
 }  // namespace cf
@@ -846,7 +904,7 @@ extern "C" int cf_conv2d_f16s(const float* x1, int C1, const float* x2, int C2, 
     p.gn_ws = gn_ws; p.gn_groups = gn_groups < 0 ? -gn_groups : gn_groups; p.gn_prezeroed = gn_groups < 0;
     CF_REQUIRE(!gn_ws || (p.gn_groups > 0 && Cout % p.gn_groups == 0 && out_coff == 0 && out_ctotal == Cout), "bad GroupNorm statistics request");
     CF_REQUIRE(p.Ho > 0 && p.Wo > 0, "empty output");
-    CF_REQUIRE(conv_f16s_supported(p), "unsupported configuration for the f16-split kernel (3x3 pad 1 or 1x1 pad 0, stride 1/2)");
+    CF_REQUIRE(conv_f16s_supported(p), "unsupported configuration for the f16-split kernel (3x3 pad 1 or 1x1 pad 0 at stride 1/2, 1x5 pad (0,2) or 5x1 pad (2,0) at stride 1; one sample < 2 GiB)");
     return launch_conv_f16s(p, reinterpret_cast<const _Float16*>(wpk), as_stream(stream));
 }
 
@@ -897,7 +955,8 @@ extern "C" int cf_conv_transpose2d_k2s2_f16s(const float* x, const void* wpk, co
     p.x1 = x; p.x2 = nullptr; p.wt = nullptr; p.bias = bias; p.res = nullptr; p.out = out; p.w_bstride = 0;
     p.C1 = Cin; p.C2 = 0; p.B = B; p.H = H; p.W = W; p.Cout = Cout * 4; p.KH = 1; p.KW = 1; p.stride = 1;
     p.pad_h = 0; p.pad_w = 0; p.Ho = H; p.Wo = W; p.out_ctotal = out_ctotal; p.out_coff = out_coff; p.act = CF_ACT_NONE;
-    p.alpha = alpha; p.scatter2x2 = 1; p.gn_ws = gn_ws; p.gn_groups = gn_groups;
-    CF_REQUIRE(!gn_ws || (gn_groups > 0 && Cout % gn_groups == 0 && out_coff == 0 && out_ctotal == Cout), "bad GroupNorm statistics request");
+    p.alpha = alpha; p.scatter2x2 = 1; p.gn_ws = gn_ws; p.gn_groups = gn_groups < 0 ? -gn_groups : gn_groups; p.gn_prezeroed = gn_groups < 0;
+    CF_REQUIRE(!gn_ws || (p.gn_groups > 0 && Cout % p.gn_groups == 0 && out_coff == 0 && out_ctotal == Cout), "bad GroupNorm statistics request");
+    CF_REQUIRE(conv_f16s_supported(p), "unsupported configuration for the f16-split kernel (one sample of the input must stay below 2 GiB)");
     return launch_conv_f16s(p, reinterpret_cast<const _Float16*>(wpk), as_stream(stream));
 }

@@ -478,6 +478,8 @@ extern "C" int cf_corr_pyramid(const float* f1, const float* f2, float* pyr, int
     p.C1 = C; p.C2 = 0; p.B = B; p.H = H; p.W = W; p.Cout = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad_h = 0; p.pad_w = 0;
     p.Ho = H; p.Wo = W; p.out_ctotal = N; p.out_coff = 0; p.act = CF_ACT_NONE; p.alpha = (float)(1.0 / sqrt((double)C));
     p.scatter2x2 = 0; p.gn_ws = nullptr; p.gn_groups = 0;
+    // algorithmic bytes: read f1 and f2 once, write the N x N volume once; each pooled level written once
+    p.profile_kid = PK_ALLPAIRS; p.profile_work = 4.0 * B * (2.0 * C * N + (double)N * N);
     int rc = launch_conv(p, s);
     if (rc != CF_OK) return rc;
     long off = 0;
@@ -487,7 +489,7 @@ extern "C" int cf_corr_pyramid(const float* f1, const float* f2, float* pyr, int
         const float* in = pyr + off;
         off += planes * Hl * Wl;
         long total = planes * (Hl >> 1) * (Wl >> 1);
-        hipLaunchKernelGGL(avgpool2x2_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, s, in, pyr + off, planes, Hl, Wl);
+        launch_profiled(PK_ALLPAIRS, 4.0 * total, avgpool2x2_kernel, dim3(flat_grid(total, 256)), dim3(256), s, in, pyr + off, planes, Hl, Wl);
         CF_CHECK_LAUNCH();
     }
     return CF_OK;
@@ -499,8 +501,9 @@ extern "C" int cf_corr_lookup(const float* pyr, const float* coords, float* out,
     CF_REQUIRE(B > 0 && H > 0 && W > 0 && levels >= 1 && levels <= 6 && radius >= 0 && radius <= 8, "bad shape");
     CF_REQUIRE((H >> (levels - 1)) >= 2 && (W >> (levels - 1)) >= 2, "coarsest level must be at least 2x2");
     long total = (long)B * levels * (2 * radius + 1) * (2 * radius + 1) * H * W;
-    hipLaunchKernelGGL(corr_lookup_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, as_stream(stream), pyr, coords, out, B, H, W,
-                       levels, radius);
+    // algorithmic bytes: the written channels + coords once; the gathers (<= 4 per output) are cache traffic
+    launch_profiled(PK_CORR_LOOKUP, 4.0 * total + 8.0 * B * H * W, corr_lookup_kernel, dim3(flat_grid(total, 256)), dim3(256), as_stream(stream), pyr,
+                    coords, out, B, H, W, levels, radius);
     CF_CHECK_LAUNCH();
     return CF_OK;
 }
@@ -509,7 +512,9 @@ extern "C" int cf_convex_upsample(const float* flow, const float* mask, float* o
     CF_REQUIRE(flow && mask && out, "null pointer");
     CF_REQUIRE(B > 0 && C > 0 && h > 0 && w > 0, "bad shape");
     long total = (long)B * 64 * h * w;
-    hipLaunchKernelGGL(convex_upsample_kernel, dim3(flat_grid(total, 256)), dim3(256), 0, as_stream(stream), flow, mask, out, B, C, h, w);
+    // algorithmic bytes: read the 576-channel mask and the coarse field once, write the 8x upsampled field once
+    launch_profiled(PK_CONVEX_UP, 4.0 * B * h * w * (576.0 + C + 64.0 * C), convex_upsample_kernel, dim3(flat_grid(total, 256)), dim3(256),
+                    as_stream(stream), flow, mask, out, B, C, h, w);
     CF_CHECK_LAUNCH();
     return CF_OK;
 }

@@ -271,15 +271,17 @@ extern "C" int cf_fill_holes(uint8_t* mask, const int* labels, int* touch, int D
     return CF_OK;
 }
 
+// {min, max} pairs start at {INT_MAX, -1}; written by a kernel on the caller's stream (a host-to-device copy of a stack array needed a
+// stream synchronisation here, against the library's own "no host sync" rule)
+__global__ void bbox_init_kernel(int* bbox) {
+    if (threadIdx.x < 6) bbox[threadIdx.x] = (threadIdx.x & 1) ? -1 : INT_MAX;
+}
+
 extern "C" int cf_mask_bbox(const uint8_t* mask, int D, int H, int W, int* bbox, void* stream) {
     CF_REQUIRE(mask && bbox, "null pointer");
     CF_REQUIRE(D > 0 && H > 0 && W > 0 && (long)D * H * W < (1L << 31) - 1, "bad shape");
-    const int init[6] = {INT_MAX, -1, INT_MAX, -1, INT_MAX, -1};
     hipStream_t s = as_stream(stream);
-    if (hipMemcpyAsync(bbox, init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-        set_error("cf_mask_bbox: init copy failed");
-        return CF_ERR_LAUNCH;
-    }
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, s, bbox);
     const long n = (long)D * H * W;
     hipLaunchKernelGGL(mask_bbox_kernel, dim3(flat_grid(n, 256, 16)), dim3(256), 0, s, mask, D, H, W, bbox);
     CF_CHECK_LAUNCH();

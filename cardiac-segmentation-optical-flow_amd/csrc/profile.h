@@ -12,7 +12,11 @@ enum ProfileKernel {
     PK_CONV_MT1 = 0, PK_CONV_MT2 = 1, PK_CONV_MT4 = 2,      // work = flops
     PK_CORRVOL_S1 = 3, PK_CORRVOL_S2 = 4, PK_CORRVOL_S4 = 5, // work = algorithmic bytes
     PK_CONV_F16S = 6,                                        // work = flops
-    PK_COUNT = 7
+    PK_ALLPAIRS = 7,                                         // RAFT all-pairs volume + pyramid pooling; work = algorithmic bytes
+    PK_CORR_LOOKUP = 8,                                      // RAFT correlation lookup; work = algorithmic bytes
+    PK_CONVEX_UP = 9,                                        // RAFT convex upsampling; work = algorithmic bytes
+    PK_GN_APPLY = 10,                                        // GroupNorm apply passes; work = algorithmic bytes
+    PK_COUNT = 11
 };
 
 bool profile_on();

@@ -111,10 +111,18 @@ int cf_conv2d(const float* x1, int C1, const float* x2, int C2, const float* wt,
               int KW, int stride, int pad_h, int pad_w, int act, float alpha, void* stream);
 
 /* Same operator on the f16 MFMA with a 3-term hi/lo operand split (conv_f16s.hip): ~2^-22 relative operand error
- * (fp32-class accuracy, measured in DESIGN.md) at up to 5.3x the fp32-MFMA rate.  Supported: 3x3 pad 1 or 1x1 pad 0,
- * stride 1 or 2; anything else returns CF_ERR_ARG and the caller uses cf_conv2d.  `wpk` = weights packed by the host
+ * (fp32-class accuracy, measured in DESIGN.md) at up to 5.3x the fp32-MFMA rate.  Supported: 3x3 pad 1 or 1x1 pad 0 at
+ * stride 1 or 2, and the separable 1x5 pad (0,2) / 5x1 pad (2,0) convolutions of RAFT's SepConvGRU at stride 1; anything
+ * else returns CF_ERR_ARG (the caller decides: cf_conv2d is the exact fp32 operator).  `wpk` = weights packed by the host
  * in MFMA fragment order as fp16 hi/lo planes and pre-scaled by 2^s (cineflow/ops.py pack_conv_weight_f16s);
- * pass alpha * 2^-s as `alpha`.
+ * pass alpha * 2^-s as `alpha`.  With a second input (C2 > 0) whose split C1 is not a multiple of the chunk size (16
+ * channels for 3x3, 32 otherwise) the weights must be packed split-aware (pack_conv_weight_f16s(w, c1=C1): x1's channels
+ * padded to whole chunks) -- the kernel switches input pointers at a chunk boundary.
+ * Sizes: the kernel addresses its inputs with 32-bit offsets; ONE SAMPLE of x1 / x2 must stay below 2 GiB, a batch of any
+ * size is cut into sub-batches inside the library (same kernel, same numbers).
+ * Activation range: |x| < 65504 (fp16's range for the hi half).  Larger magnitudes, Inf and NaN are not clamped: they come
+ * out as NaN, as loudly as in an fp32 convolution fed with NaN.  Below 2^-14 |x| the lo half goes subnormal (absolute error
+ * 2^-25), which is under the fp32 rounding of the sum for the normalised activations this path is built for.
  * gn_ws (nullable, 2*B*gn_groups doubles): on return it holds the GroupNorm / InstanceNorm statistics (sum, sum of squares
  * per (sample, group)) of the OUTPUT, accumulated in the conv epilogue (or by a statistics pass when a workgroup spans
  * several samples); feed it to cf_group_norm_apply.  Requires a dense output (out_coff 0, out_ctotal == Cout).
@@ -303,7 +311,8 @@ int cf_ssim_map(const double* im1, const double* im2, int H, int W, int win, dou
  * cf_profile_enable(n): pre-create n event pairs and time every conv / CorrVolume launch with a (start, stop) pair that
  * brackets exactly that kernel on its own stream (hipExtLaunchKernelGGL); 0 disables.  Kernel ids:
  * 0,1,2 = conv_igemm MT 1,2,4 (work = flops); 3,4,5 = corr_volume_p7 stride 1,2,4 (work = algorithmic bytes);
- * 6 = conv_f16s (work = flops).
+ * 6 = conv_f16s (work = flops); 7 = RAFT all-pairs volume + pyramid pooling, 8 = RAFT correlation lookup, 9 = convex
+ * upsampling, 10 = GroupNorm apply passes (work = algorithmic bytes).
  * cf_profile_read sums kernel durations [ms], work and launches since the last cf_profile_reset (it synchronises: call it
  * outside the timed region). */
 int cf_profile_enable(int max_launches);

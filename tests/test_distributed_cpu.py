@@ -52,3 +52,33 @@ def test_two_rank_gloo():
     assert res[0][2] == [0, 2, 4, 6] and res[1][2] == [1, 3, 5]
     assert res[0][3] == res[1][3] == 2.0
     assert res[0][4] == res[1][4] == 7.0
+
+
+def _run_bench(*args):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(args), env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_self_launch_dry_run_two_ranks():
+    """`python bench.py --gpus 2` starts its own ranks (the driver's contract): dry-run mode goes through the launcher, the
+    rendezvous, the flat weight broadcast of the full-size networks, the barrier and the max-over-ranks reduction on gloo and
+    prints exactly ONE JSON line from rank 0."""
+    import json
+    r = _run_bench("--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["dry_run"] is True and d["scaling"] == "weak"
+    assert d["weights_identical_on_all_ranks"] is True and d["ranks_reporting"] == 2
+    assert d["ms_per_step"] >= 20.0          # rank 1 sleeps 20 ms per step: the MAX over ranks is reported
+
+
+def test_bench_self_launch_propagates_rank_failure():
+    """a rank that fails (here: no GPU in the build container) makes the launcher exit non-zero and print no JSON line"""
+    r = _run_bench("--gpus", "2", "--steps", "1", "--no-raft")
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]

@@ -301,3 +301,100 @@ def test_joint_cine_pipeline_vs_oracle(dev):
     for k in range(4):
         d = OO.dice(out["registered"].cpu().numpy(), reg.numpy(), k)
         assert np.isnan(d) or abs(d - 1.0) <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ full size / long recurrence
+def smooth_cine(T_, B, S_, seed):
+    """z-scored synthetic cine frames of the bench (annulus + blobs + noise): realistic flows, not white noise"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.synthetic_cine(B, T_, S_, seed)
+
+
+def drift_curve(out, ref):
+    """mean EPE per recurrence step: out / ref [T-1,B,2,H,W]"""
+    return [float(torch.sqrt(((out[t].cpu().double() - ref[t].double()) ** 2).sum(1)).mean()) for t in range(out.shape[0])]
+
+
+def test_raft_full_size_12_iterations_vs_oracle(dev):
+    """BASELINE config 3 at full size: SegFlowGaussian(raft=True, raft_iters=12), full width, 256x256 (feature maps
+    [B,256,32,32], 4-level all-pairs pyramid), two frame pairs in sequence, against the CPU oracle.  Parity unpinned for the update
+    block / CorrBlock themselves (published RAFT, source absent from the reference); the bar is the north star's 1e-4 px mean EPE,
+    asserted for EVERY iteration's up-sampled flow (the GRU state carries over 24 update steps)."""
+    from cineflow.models import SegFlowGaussian
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    kw = dict(image_size=256, motion_appearance=False, dim_feedforward=2048, raft=True, raft_iters=12)
+    m = load(SegFlowGaussian(**kw), 31, dev)
+    ora = fill_module_(OM.SegFlowGaussian(**kw), 31)
+    frames = smooth_cine(3, 2, 256, 5)
+    out = m(frames.to(dev))["backward_flow"].cpu()
+    with torch.no_grad():
+        ref = ora(frames)["backward_flow"]
+    assert out.shape == ref.shape == (12, 2, 2, 2, 256, 256)
+    assert float(ref[-1].abs().mean()) > 1.0, "degenerate test: the flow should be pixels, not zeros"
+    curve = [max(drift_curve(out[:, t], ref[:, t])) for t in range(2)]
+    per_iter = drift_curve(out[:, 1], ref[:, 1])
+    print("RAFT full size: mean EPE per iteration (second pair) " + " ".join("%.1e" % e for e in per_iter))
+    assert max(curve) <= 1e-4, "mean EPE %.3e px (|flow| mean %.2f)" % (max(curve), float(ref.abs().mean()))
+
+
+def test_long_recurrence_reduced_width_T30(dev):
+    """30-frame recurrence (cumulated += flow, ConvGRU state, memory encoder fed with the warped error) at reduced width: the per-step
+    drift of the f16-split path against the fp32 CPU oracle stays under the 1e-4 px bar at every step, for both dispatches."""
+    from cineflow.models import SegFlowGaussian
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    for ma, ff in ((False, 48), (True, 64)):
+        kw = dict(image_size=S, d_model=32, bottleneck_heads=4, dim_feedforward=ff, motion_appearance=ma, **RED)
+        m = load(SegFlowGaussian(**kw), 11, dev)
+        ora = fill_module_(OM.SegFlowGaussian(**kw), 11)
+        frames = smooth_cine(30, 2, S, 7)
+        out = m(frames.to(dev))["backward_flow"]
+        with torch.no_grad():
+            ref = ora(frames)["backward_flow"]
+        curve = drift_curve(out, ref)
+        print("T=30 reduced width (motion_appearance=%s): EPE step 1 %.1e, 10 %.1e, 20 %.1e, 29 %.1e; |flow| %.2f px"
+              % (ma, curve[0], curve[9], curve[19], curve[28], float(ref[-1].abs().mean())))
+        assert max(curve) <= 1e-4, "max per-step mean EPE %.3e at step %d" % (max(curve), int(np.argmax(curve)) + 1)
+
+
+def test_long_recurrence_full_width_T9(dev):
+    """The full 25 M-parameter video.yaml model over 9 frames at 256x256 (8 recurrence steps; the CPU oracle takes ~10 s): per-step
+    drift curve of the f16 hi/lo-split convolutions (the dropped lo*lo term every layer) against the fp32 oracle."""
+    from cineflow.models import SegFlowGaussian
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    kw = dict(image_size=256, motion_appearance=False, dim_feedforward=2048)
+    m = load(SegFlowGaussian(**kw), 30, dev)
+    ora = fill_module_(OM.SegFlowGaussian(**kw), 30)
+    frames = smooth_cine(9, 1, 256, 9)
+    out = m(frames.to(dev))["backward_flow"]
+    with torch.no_grad():
+        ref = ora(frames)["backward_flow"]
+    curve = drift_curve(out, ref)
+    print("T=9 full width: mean EPE per step " + " ".join("%.1e" % e for e in curve) + "; |flow| %.2f px" % float(ref[-1].abs().mean()))
+    assert max(curve) <= 1e-4, "max per-step mean EPE %.3e" % max(curve)
+
+
+def test_generic_unet_bench_width_vs_oracle(dev):
+    """The network the bench runs -- Generic_UNet(1, 32, 4, 6): 32 base features, 6 pools, 480-channel 4x4 bottleneck -- on two
+    256x256 frames against the oracle (which golden `generic_unet.npz` ties to the reference at reduced width)."""
+    from cineflow.models import Generic_UNet
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    m = load(Generic_UNet(1, 32, 4, 6), 41, dev)
+    ora = fill_module_(OM.GenericUNet2D(1, 32, 4, 6), 41)
+    x = smooth_cine(2, 1, 256, 3).reshape(2, 1, 256, 256)
+    out = m(x.to(dev)).cpu()
+    with torch.no_grad():
+        ref = ora(x)
+    scale = float(ref.abs().max())
+    assert float((out - ref).abs().max()) <= 5e-5 * max(1.0, scale), "logits max|diff| %.3e (scale %.2f)" % (float((out - ref).abs().max()), scale)
+    a, b = out.argmax(1).numpy(), ref.argmax(1).numpy()
+    for k in range(4):
+        d = OO.dice(a, b, k)
+        assert np.isnan(d) or abs(d - 1.0) <= 1e-3

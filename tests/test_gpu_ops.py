@@ -248,7 +248,13 @@ def test_conv2d(dev, case):
     assert float(big[:, :2].min()) == 7.0 and float(big[:, 2 + Cout:].max()) == 7.0
 
 
-F16S_CASES = [c for c in CONV_CASES if (c[6], c[7]) in ((3, 3), (1, 1))] + [
+F16S_CASES = [c for c in CONV_CASES if (c[6], c[7]) in ((3, 3), (1, 1), (1, 5), (5, 1))] + [
+    (2, 128, 256, 32, 32, 256, 1, 5, 1, (0, 2)), # SepConvGRU [r | z] gates, horizontal pass, full width (8-wave shape, vector staging)
+    (2, 128, 256, 32, 32, 128, 5, 1, 1, (2, 0)), # SepConvGRU candidate, vertical pass
+    (3, 40, 24, 16, 16, 48, 1, 5, 1, (0, 2)),    # 64-channel shape, split not a chunk multiple (split-aware packing), ragged batch
+    (3, 40, 24, 8, 8, 48, 5, 1, 1, (2, 0)),      # 8x8 maps: several images per workgroup
+    (1, 32, 0, 13, 18, 20, 5, 1, 1, (2, 0)),     # W % 4 != 0: scalar staging
+    (1, 32, 0, 13, 18, 20, 1, 5, 1, (0, 2)),
     (2, 64, 64, 32, 32, 64, 3, 3, 1, (1, 1)),    # cat[skip, up] 128 -> 64
     (1, 256, 0, 32, 32, 256, 3, 3, 1, (1, 1)),
     (3, 128, 0, 64, 64, 256, 3, 3, 2, (1, 1)),   # strided, tile rows not dividing
@@ -274,15 +280,11 @@ def test_conv2d_f16s(dev, case):
     x2 = randn(B, C2, H, W, seed=31) if C2 else None
     w = randn(Cout, C1 + C2, kh, kw, seed=32) / math.sqrt((C1 + C2) * kh * kw)
     b = randn(Cout, seed=33)
-    if not ops.f16s_dynamic_ok(x1, x2, kh):
-        # a channel chunk would straddle cat[x1,x2]: the library must refuse (the module layer then uses the fp32 kernel)
-        wpk, ws = ops.pack_conv_weight_f16s(w.to(dev))
-        with pytest.raises(Exception):
-            ops.conv2d_f16s(x1.to(dev), wpk, ws, b.to(dev), Cout, kh, kw, stride, pad, x2=x2.to(dev))
-        return
+    assert ops.f16s_supported(kh, kw, stride, pad) and ops.f16s_dynamic_ok(x1, x2, kh)
     xin = x1 if x2 is None else torch.cat([x1, x2], 1)
     ref = F.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding=pad)
-    wpk, ws = ops.pack_conv_weight_f16s(w.to(dev))
+    # a cat[x1, x2] whose split is not a chunk multiple is packed split-aware (x1's channels padded to whole chunks): same kernel
+    wpk, ws = ops.pack_conv_weight_f16s(w.to(dev), c1=C1 if C2 else None)
     out = ops.conv2d_f16s(x1.to(dev), wpk, ws, b.to(dev), Cout, kh, kw, stride, pad, x2=None if x2 is None else x2.to(dev))
     check(out, ref, 1e-5, "conv_f16s")
     res = randn(*ref.shape, seed=34)
@@ -291,6 +293,39 @@ def test_conv2d_f16s(dev, case):
                     res=res.to(dev), out=big, out_coff=2)
     check(big[:, 2:2 + Cout], F.gelu(ref) + res, 1e-5, "conv_f16s epilogue")
     assert float(big[:, :2].min()) == 7.0 and float(big[:, 2 + Cout:].max()) == 7.0
+
+
+def test_conv2d_f16s_batch_split(dev):
+    """Inputs of 2 GiB and more (32-bit buffer offsets inside the kernel): the library cuts the batch into sub-batches itself --
+    same kernel, same numbers as the per-sample calls, fused statistics and residual included."""
+    from cineflow import ops
+    B, C, H, W, Cout = 9, 64, 1024, 1024, 16         # 9 x 256 MiB = 2.25 GiB input
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(9 * C)).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    wpk, ws = ops.pack_conv_weight_f16s(w)
+    assert x.numel() * 4 >= 2 ** 31
+    out, st = ops.conv2d_f16s(x, wpk, ws, b, Cout, 3, 3, 1, (1, 1), act="relu", stats_groups=4)
+    for i in (0, 7, 8):                                # first sub-batch, its last sample, the second sub-batch
+        oi, si = ops.conv2d_f16s(x[i:i + 1], wpk, ws, b, Cout, 3, 3, 1, (1, 1), act="relu", stats_groups=4)
+        assert torch.equal(out[i:i + 1], oi)
+        assert torch.allclose(st.view(B, 4, 2)[i], si.view(4, 2), rtol=1e-12, atol=0)
+    ref = F.relu(F.conv2d(x[8:9].cpu().double(), w.cpu().double(), b.cpu().double(), padding=1))
+    check(out[8:9], ref, 1e-5, "batch split")
+
+
+def test_conv2d_f16s_nonfinite_inputs_propagate(dev):
+    """NaN / Inf activations and values beyond fp16's range come out as NaN (loud), never as silently saturated numbers."""
+    from cineflow import ops
+    x = torch.zeros(1, 16, 8, 8)
+    x[0, 3, 2, 2] = float("nan")
+    x[0, 5, 6, 6] = 1e6
+    w = torch.ones(16, 16, 3, 3) / 144
+    wpk, ws = ops.pack_conv_weight_f16s(w.to(dev))
+    out = ops.conv2d_f16s(x.to(dev), wpk, ws, None, 16, 3, 3, 1, (1, 1)).cpu()
+    assert torch.isnan(out[0, :, 1:4, 1:4]).all() and torch.isnan(out[0, :, 5:8, 5:8]).all()
+    assert torch.isfinite(out[0, :, 0, 4:]).all()
 
 
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,stride,groups", [

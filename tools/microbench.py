@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel micro-benchmarks on the shapes of the BASELINE workload (B = slices per step).
-Usage: python tools/microbench.py [--batch 16] [--only conv|gn|corr|attn|warp|pre|metrics|stem]"""
+Usage: python tools/microbench.py [--batch 16] [--only conv|gn|corr|attn|warp|pre|metrics|stem|raft]"""
 import argparse
 import math
 import os
@@ -151,6 +151,44 @@ def main():
             by = 4.0 * Bs * 65536 * (Cin + Cout)
             print("  B%3d C%d -> %2d k%d: direct %8.1f us %6.0f GB/s | f16s %8.1f us %6.0f GB/s" % (Bs, Cin, Cout, K, t1 * 1e6, by / t1 / 1e9, t2 * 1e6,
                                                                                                by / t2 / 1e9))
+
+    if args.only in ("", "raft"):
+        # BASELINE config 3: the kernels of one RAFT frame pair at 256x256 (feature maps [B,256,32,32]), B = 4 x --batch pairs
+        Br = 4 * B
+        print("== RAFT (config 3), B = %d frame pairs, fmaps [B,256,32,32]" % Br)
+        f1, f2 = torch.randn(Br, 256, 32, 32, generator=g).to(dev), torch.randn(Br, 256, 32, 32, generator=g).to(dev)
+        t = timeit(lambda: ops.corr_pyramid(f1, f2, 4))
+        by = Br * 4.0 * (2 * 256 * 1024 + 1024 * 1024 * (1 + 1 / 4 + 1 / 16 + 1 / 64))
+        print("  all-pairs volume + 4-level pyramid: %8.1f us  %6.0f GB/s algorithmic (7.67 MB / pair)  %6.1f TFLOP/s" %
+              (t * 1e6, by / t / 1e9, 2.0 * Br * 1024 * 1024 * 256 / t / 1e12))
+        pyr = ops.corr_pyramid(f1, f2, 4)
+        coords = ops.coords_grid(Br, 32, 32, dev) + 3 * torch.randn(Br, 2, 32, 32, generator=g).to(dev)
+        t = timeit(lambda: ops.corr_lookup(pyr, coords, 4, 4))
+        print("  correlation lookup (324 ch): %8.1f us  %6.0f GB/s algorithmic (1.33 MB written / pair)" % (t * 1e6, Br * 4.0 * (324 + 2) * 1024 / t / 1e9))
+        flow, mask = torch.randn(Br, 2, 32, 32, generator=g).to(dev), torch.randn(Br, 576, 32, 32, generator=g).to(dev)
+        t = timeit(lambda: ops.convex_upsample(flow, mask))
+        print("  convex upsample: %8.1f us  %6.0f GB/s algorithmic (2.36 MB mask + 0.52 MB out / pair)" % (t * 1e6, Br * 4.0 * 1024 * (576 + 2 + 128) / t / 1e9))
+        print("  update-block convolutions at 32x32 (algorithmic TFLOP/s): f16s split vs exact fp32 MFMA")
+        for (name, C1, C2, Cout, kh, kw) in [("convc1 1x1", 324, 0, 256, 1, 1), ("convc2 3x3", 256, 0, 192, 3, 3), ("convf1 7x7", 2, 0, 128, 7, 7),
+                                            ("convf2 3x3", 128, 0, 64, 3, 3), ("conv 3x3", 192, 64, 126, 3, 3), ("gru rz 1x5", 128, 256, 256, 1, 5),
+                                            ("gru q 1x5", 128, 256, 128, 1, 5), ("gru rz 5x1", 128, 256, 256, 5, 1), ("gru q 5x1", 128, 256, 128, 5, 1),
+                                            ("flow head 3x3", 128, 0, 256, 3, 3), ("flow head 256->2", 256, 0, 2, 3, 3), ("mask 3x3", 128, 0, 256, 3, 3),
+                                            ("mask 1x1", 256, 0, 576, 1, 1)]:
+            x1 = torch.randn(Br, C1, 32, 32, generator=g).to(dev)
+            x2 = torch.randn(Br, C2, 32, 32, generator=g).to(dev) if C2 else None
+            w = (torch.randn(Cout, C1 + C2, kh, kw, generator=g) / math.sqrt((C1 + C2) * kh * kw)).to(dev)
+            pad = (kh // 2, kw // 2)
+            out = torch.empty(Br, Cout, 32, 32, device=dev)
+            fl = 2.0 * Br * 1024 * Cout * (C1 + C2) * kh * kw
+            wt = ops.prep_conv_weight(w)
+            t32 = timeit(lambda: ops.conv2d(x1, wt, None, Cout, kh, kw, 1, pad, x2=x2, out=out), iters=3, warm=1)
+            if ops.f16s_supported(kh, kw, 1, pad):
+                wpk, wsc = ops.pack_conv_weight_f16s(w, c1=C1 if C2 else None)
+                t16 = timeit(lambda: ops.conv2d_f16s(x1, wpk, wsc, None, Cout, kh, kw, 1, pad, x2=x2, out=out))
+                print("    %-18s %3d+%-3d -> %3d | f16s %8.1f us %7.1f TF | fp32 %8.1f us %6.1f TF" % (name, C1, C2, Cout, t16 * 1e6, fl / t16 / 1e12,
+                                                                                                 t32 * 1e6, fl / t32 / 1e12))
+            else:
+                print("    %-18s %3d+%-3d -> %3d | (fp32 kernel by design)           | fp32 %8.1f us %6.1f TF" % (name, C1, C2, Cout, t32 * 1e6, fl / t32 / 1e12))
 
     if args.only in ("", "metrics"):
         # the per-case work of compute_metrics.py (3 classes x Dice / HD / ASSD) on one ACDC-sized label volume, device vs CPU oracle
