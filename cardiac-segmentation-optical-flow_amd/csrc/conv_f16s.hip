@@ -43,6 +43,7 @@ struct F16sGeom {
     int ostep;               // patch step between output pixels (stride, or 1 for 1x1 convs)
     int tiles_x, tiles_y, bgroups;
     int nchunk;
+    int ablate;              // timing experiments only (CF_F16S_ABLATE): 1 = every chunk reads chunk 0's weight fragments (L1-resident), 2 = no fragment loads
     int c1_pad;              // C1 rounded up to a multiple of CK: chunks below it read x1, the others x2 (the packed weights follow the same split)
     int NQ;                  // vector staging: 16-byte column quads per patch row (0: scalar staging)
     // magic multipliers floor(2^32/d)+1 for the index decodes (exact for n < 2^32/d; d == 1 handled apart): the kernel's setup was
@@ -67,7 +68,12 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 // chunks of loads in flight, always one LDS buffer ahead.  vmcnt retires in issue order, so in the mixed design every
 // wait for a weight fragment also waited for the staging loads issued before it (ablating those loads made the kernel
 // 19-33 % faster); with separate roles nothing in the MFMA waves ever waits for HBM.
-template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE>
+// WL = 1: the weight fragments go through LDS instead of straight from L1/L2 into registers.  Ablations (profiles/r02_conv_weight_path.md)
+// showed that the per-wave fragment loads -- 2 KiB per k-step and wave, L1-resident or not -- cost 30-40 % of the kernel on every shape:
+// the vector-memory return path (64 B/clk/CU) is what the MFMAs wait for.  With WL the workgroup fetches each fragment ONCE by LDS-DMA
+// (global_load_lds_dwordx4, no VGPRs) into a two-slot ring of tap groups (3x3: one kernel row = 3 taps per slot) and every wave reads
+// its A operands with ds_read_b128 (256 B/clk/CU); one barrier per group, the DMA of group q + 1 is in flight while group q is consumed.
+template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE, int WL>
 __global__ void __launch_bounds__(64 * NW + 64 * NLW, NLW ? 5 : (NW == 8 ? 4 : ((NTW <= 2 && MAXT <= 3) ? 4 : 2)))
 conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restrict__ wpk) {
     constexpr int KHW = KH * KW;           // taps: 3x3, 1x1, and the separable 1x5 / 5x1 of RAFT's SepConvGRU
@@ -332,16 +338,101 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[nt][r] = 0.f;
 
+    constexpr int NSTEP = KHW * KS;
+    if constexpr (WL) {
+        // ---- weights through LDS: ring of two slots, one slot = the fragments of G consecutive k-steps for the WM m-tiles of the workgroup
+        constexpr int G = (KHW == 9) ? 3 : ((KHW == 1) ? NSTEP : 5);      // k-steps per group (3x3: one kernel row)
+        constexpr int NGRP = NSTEP / G;
+        static_assert(NGRP * G == NSTEP, "weight groups must tile the chunk");
+        constexpr int WSLOT = WM * G * 2 * 1024;                          // bytes per slot
+        unsigned char* wl = lds + 2 * buf_bytes + (PRE ? 3 * ctab_n * 4 : 0);
+        const f16x8* wbase = reinterpret_cast<const f16x8*>(wpk) + lane;
+        const int nq = g.nchunk * NGRP;
+        // The DMA is issued from inline asm on purpose: hipcc tracks a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
+        // s_waitcnt vmcnt(0) in front of the next ds_read that may alias it -- i.e. it waited for group q + 1 before reading group q
+        // (measured: 20 % of the kernel).  Hidden from the compiler, the DMAs only make ITS counted vmcnt waits stricter (vmcnt counts
+        // every outstanding operation and retires in order), never weaker; their own completion is waited for explicitly below.
+        auto issue_w = [&](int q) {       // group q = (chunk q / NGRP, steps (q % NGRP) * G ...): packed contiguously per m-tile
+            const unsigned dst0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)(wl + (q & 1) * WSLOT));
+            for (int f = wave; f < WM * G * 2; f += NW) {                 // wave-uniform
+                const int m = f / (G * 2), j = f - m * (G * 2);
+                const f16x8* src = wbase + (((long)(blockIdx.y * WM + m) * g.nchunk * NSTEP + (long)q * G) * 2 + j) * 64;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(dst0 + (unsigned)f * 1024u);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            }
+        };
+        issue_w(0);
+        if (PRE) {
+            float* ct = reinterpret_cast<float*>(lds + 2 * buf_bytes);
+            for (int k = tid; k < 3 * ctab_n; k += 64 * NW) {
+                const int which = k / ctab_n, c = k - which * ctab_n;
+                ct[k] = c < p.C1 ? p.in_norm[((long)b0 * 3 + which) * p.C1 + c] : 0.f;
+            }
+            __syncthreads();
+        }
+        if (VEC) write_stage_v(0, stgv);
+        else write_stage(0, stg0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // group 0's fragments have landed
+        __syncthreads();
+        const unsigned char* wa = wl + ((cw % WM) * G * 2) * 1024 + lane * 16;
+        for (int c = 0; c < g.nchunk; ++c) {
+            const bool more = c + 1 < g.nchunk;
+            const unsigned char* xb = lds + (c & 1) * buf_bytes;
+#pragma unroll
+            for (int grp = 0; grp < NGRP; ++grp) {
+                const int q = c * NGRP + grp;
+                if (q + 1 < nq && g.ablate != 3) issue_w(q + 1);
+                if (grp == 0 && more) {           // (younger than the DMAs: the counted wait at the end of this group leaves them in flight)
+                    if (VEC) issue_loads_v(c + 1, stgv);
+                    else issue_loads(c + 1, stg0);
+                }
+                const unsigned char* ws = wa + (q & 1) * WSLOT;
+#pragma unroll
+                for (int sg = 0; sg < G; ++sg) {
+                    const int step = grp * G + sg;
+                    const int tap = step / KS, ks = step % KS;
+                    const int ky = tap / KW, kx = tap % KW;
+                    const int toff = (ky * g.PWR + (g.pwh ? (kx >> 1) + (kx & 1) * g.pwh : kx)) * REC;
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(ws + (sg * 2) * 1024);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(ws + (sg * 2 + 1) * 1024);
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const unsigned char* rp = xb + b_rec[nt] + toff + ks * 32;
+                        const f16x8 bh = *reinterpret_cast<const f16x8*>(rp);
+                        const f16x8 bl = *reinterpret_cast<const f16x8*>(rp + CK * 2);
+                        acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+                        acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                        acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nt], 0, 0, 0);
+                    }
+                }
+                if (grp == NGRP - 1 && more) {
+                    if (VEC) write_stage_v(c + 1, stgv);
+                    else write_stage(c + 1, stg0);
+                }
+                // group q + 1's fragments must have landed before anyone reads them: vmcnt retires in order, so at the end of group 0 the
+                // patch loads issued after the DMAs (VEC: 4 per task) may stay in flight
+                if (VEC && grp == 0 && NGRP > 1) {
+                    if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VEC * 4) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (g.ablate != 4 || grp == NGRP - 1) __syncthreads();
+            }
+        }
+    } else {
     // packed weights: fragment (mt, chunk, tap, ks, part) = 64 lanes x 8 halves
     const f16x8* wfrag = reinterpret_cast<const f16x8*>(wpk) + (long)mt * g.nchunk * (KHW * KS * 2) * 64 + lane;
 
     // A-fragment register ring, prefetched D steps ahead (NSTEP % R == 0 keeps the slots static).
-    constexpr int NSTEP = KHW * KS;
     constexpr int R = (NSTEP % 3 == 0) ? 3 : 2;
     constexpr int D = R - 1;
-    f16x8 aH[R], aL[R];
+    f16x8 aH[R] = {}, aL[R] = {};
     auto load_a = [&](int chunk, int step, int slot) {
-        const f16x8* wc = wfrag + ((long)chunk * NSTEP + step) * 2 * 64;
+        if (g.ablate == 2) return;
+        const f16x8* wc = wfrag + ((long)(g.ablate == 1 ? 0 : chunk) * NSTEP + step) * 2 * 64;
         aH[slot] = wc[0];
         aL[slot] = wc[64];
     };
@@ -397,6 +488,8 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
             else write_stage(c + 1, stg0);
         }
         __syncthreads();
+    }
+
     }
 
     // ---- epilogue (same fusion as conv.hip): value = act(alpha*acc + bias) + res  (alpha carries the weight scale 2^-s)
@@ -591,7 +684,7 @@ static int f16s_vec() {
     return v;
 }
 
-template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE = 0>
+template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE = 0, int WL = 0>
 static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s);
 
 // picks the vector-staging instantiation when the layer qualifies (stride 1, W % 4 == 0, 16-byte aligned inputs, VT 4x4 tasks per
@@ -629,11 +722,13 @@ static int launch_f16s(const ConvParams& p, F16sGeom g, const _Float16* wpk, hip
     return launch_f16s_v<KH, KW, CK, WM, NTW, MAXT, NLW, NW, 0>(p, g, wpk, s);
 }
 
-template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE>
+template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE, int WL>
 static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s) {
     constexpr int REC = CK * 4 + 16;
+    constexpr int WGRP = (KH * KW == 9) ? 3 : ((KH * KW == 1) ? CK / 16 : 5);      // k-steps per LDS weight slot (kernel: G)
     constexpr int NSTAGE = NLW ? 64 * NLW : 64 * NW;
     const int nrec = g.NIMG * g.PH * g.PW;
+    { static int ab = -1; if (ab < 0) { const char* e = getenv("CF_F16S_ABLATE"); ab = e ? atoi(e) : 0; } g.ablate = ab; }
     g.m_tx = f16s_magic(g.tiles_x);
     g.m_ty = f16s_magic(g.tiles_y);
     g.m_percg = f16s_magic(g.NIMG * g.PH * g.NQ);
@@ -652,13 +747,14 @@ static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, h
         set_error("conv_f16s: staging tasks exceed MAXT");
         return CF_ERR_ARG;
     }
-    const size_t lds_bytes = (size_t)2 * g.NIMG * g.PH * g.PWR * REC + (PRE ? (size_t)3 * g.nchunk * CK * sizeof(float) : 0);
+    const size_t lds_bytes = (size_t)2 * g.NIMG * g.PH * g.PWR * REC + (PRE ? (size_t)3 * g.nchunk * CK * sizeof(float) : 0) +
+                             (WL ? (size_t)2 * WM * WGRP * 2 * 1024 : 0);
     if (lds_bytes > 160 * 1024) {
         set_error("conv_f16s: LDS tile too large");
         return CF_ERR_ARG;
     }
     if (p.probe) return CF_OK;
-    auto kern = conv_f16s_kernel<KH, KW, CK, WM, NTW, MAXT, NLW, NW, VEC, PRE>;
+    auto kern = conv_f16s_kernel<KH, KW, CK, WM, NTW, MAXT, NLW, NW, VEC, PRE, WL>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -678,6 +774,33 @@ static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, h
         return CF_ERR_LAUNCH;
     }
     return CF_OK;
+}
+
+// The weights-through-LDS shapes (3x3, stride 1, vector staging, one sample per workgroup, 8 waves).  Returns -1 when the layer does not
+// qualify (the caller then takes the register-fragment shapes).
+template <int WM, int NTW>
+static int launch_f16s_wl(const ConvParams& p, F16sGeom g, const _Float16* wpk, hipStream_t s, bool* probe_single) {
+    constexpr int CK = 16, NW = 8;
+    if (!(f16s_vec() && p.stride == 1 && (p.W & 3) == 0 && (g.TW & 3) == 0 && g.NIMG == 1 &&
+          ((reinterpret_cast<uintptr_t>(p.x1) | reinterpret_cast<uintptr_t>(p.x2)) & 15) == 0))
+        return -1;
+    const int a = (-p.pad_w) & 3;
+    const int nq = ((a + g.PW - 1) >> 2) + 1;
+    if ((CK / 4) * g.NIMG * g.PH * nq > 64 * NW) return -1;
+    g.NQ = nq;
+    if (probe_single) { *probe_single = true; return CF_OK; }      // geometry probe: the layer takes this shape, one sample per workgroup
+    if (p.in_norm) {
+        if (p.C2 != 0 || (reinterpret_cast<uintptr_t>(p.in_norm) & 3) != 0) return -1;
+        return launch_f16s_v<3, 3, CK, WM, NTW, 2, 0, NW, 1, 1, 1>(p, g, wpk, s);
+    }
+    return launch_f16s_v<3, 3, CK, WM, NTW, 2, 0, NW, 1, 0, 1>(p, g, wpk, s);
+}
+
+// CF_F16S_WL=0 keeps the weight fragments on the L1/L2 -> register path everywhere (A/B knob)
+static int f16s_wl() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CF_F16S_WL"); v = e ? atoi(e) : 1; }
+    return v;
 }
 
 // kernel shapes of the f16-split kernel: 3x3 pad 1 and 1x1 pad 0 at stride 1 / 2, and the separable 1x5 (pad 0,2) / 5x1 (pad 2,0)
@@ -796,8 +919,8 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     const bool wide = small && !s2 && f16s_wide() && p.Cout % 128 == 0 && f16s_loader_waves() == 0;
     // n-tiles (of 32 output pixels) per workgroup
     const int NT_WG = s2 ? ((small && !narrow) ? 2 : 4) : ((small || sep) ? 4 : 8);
-    const int npx = NT_WG * 32;
     F16sGeom g;
+    auto geometry = [&](int npx) {
     g.TW = p.Wo < 32 ? p.Wo : 32;
     g.TH = npx / g.TW;
     if (g.TH > p.Ho) g.TH = p.Ho;
@@ -837,6 +960,23 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     // split-aware chunking: x1's channels are padded to whole chunks (the packed weights carry zeros there), then x2's follow
     g.c1_pad = p.C2 > 0 ? ((p.C1 + CK - 1) / CK) * CK : (1 << 30);
     g.nchunk = p.C2 > 0 ? g.c1_pad / CK + (p.C2 + CK - 1) / CK : (p.C1 + CK - 1) / CK;
+    };
+    // The weights-through-LDS shapes come first (3x3, stride 1, Cout not a multiple of 128): 8 waves, 256 output pixels x 64 (or 32)
+    // channels; they need one sample per workgroup and the vector staging path, else the register-fragment shapes below take the layer.
+    // Measured (profiles/r02_conv_weight_path.md, B = 16): 64 -> 64 at 256x256 234 -> 263 TF, 32 -> 32 195 -> 205, 81 -> 64 208 -> 222; the
+    // 128-channel form of it (4 m-tiles x 2 pixel tiles per wave, 8 waves) LOSES to the four-wave shape whose fragments feed 12 MFMAs
+    // (128 -> 128 at 128x128: 294 vs 343 TF) and is not dispatched (CF_F16S_WL=2 forces it for A/B runs).
+    if (k3 && p.stride == 1 && f16s_wl() && small && f16s_loader_waves() == 0 && (p.Cout % 128 != 0 || f16s_wl() == 2)) {
+        const bool w128 = p.Cout % 128 == 0;
+        geometry(w128 ? 128 : 256);
+        if (g.NIMG == 1) {
+            const int rc = w128 ? launch_f16s_wl<4, 2>(p, g, one_sample_per_wg ? nullptr : wpk, s, one_sample_per_wg)
+                                : (narrow ? launch_f16s_wl<1, 1>(p, g, one_sample_per_wg ? nullptr : wpk, s, one_sample_per_wg)
+                                          : launch_f16s_wl<2, 2>(p, g, one_sample_per_wg ? nullptr : wpk, s, one_sample_per_wg));
+            if (rc != -1) return rc;
+        }
+    }
+    geometry(NT_WG * 32);
     if (one_sample_per_wg) {  // geometry probe
         *one_sample_per_wg = g.NIMG == 1;
         return CF_OK;

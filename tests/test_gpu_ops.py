@@ -310,7 +310,7 @@ def test_conv2d_f16s_batch_split(dev):
     for i in (0, 7, 8):                                # first sub-batch, its last sample, the second sub-batch
         oi, si = ops.conv2d_f16s(x[i:i + 1], wpk, ws, b, Cout, 3, 3, 1, (1, 1), act="relu", stats_groups=4)
         assert torch.equal(out[i:i + 1], oi)
-        assert torch.allclose(st.view(B, 4, 2)[i], si.view(4, 2), rtol=1e-12, atol=0)
+        assert torch.allclose(st.view(B, 4, 2)[i], si.view(4, 2), rtol=1e-7, atol=0)    # fp32 partial sums meet in another order
     ref = F.relu(F.conv2d(x[8:9].cpu().double(), w.cpu().double(), b.cpu().double(), padding=1))
     check(out[8:9], ref, 1e-5, "batch split")
 
