@@ -66,6 +66,9 @@ def read_nifti(path):
     slope, inter = struct.unpack_from("<2f", raw, 112)
     if code not in _DTYPES:
         raise ValueError("%s: unsupported NIfTI datatype %d" % (path, code))
+    if dim[0] > 3 and any(d > 1 for d in dim[4:1 + dim[0]]):
+        raise ValueError("%s: %d-D NIfTI (dim %s); only 3-D volumes are supported (one file per frame, as the reference's dataset "
+                         "conversion writes them)" % (path, dim[0], dim[1:1 + dim[0]]))
     nx, ny, nz = dim[1], max(dim[2], 1), max(dim[3], 1) if dim[0] >= 3 else 1
     n = nx * ny * nz
     a = np.frombuffer(raw, dtype=_DTYPES[code], count=n, offset=max(vox_offset, 352)).reshape(nz, ny, nx)
@@ -82,6 +85,23 @@ def read_nifti(path):
         D = lps2ras @ (M / sp)
         origin = lps2ras @ t
         spacing = sp
+    elif struct.unpack_from("<h", raw, 252)[0] > 0:
+        # qform only (scanner- / ITK-written files): rotation from the quaternion (b, c, d), qfac = pixdim[0] flips the third axis --
+        # the fallback ITK itself takes when sform_code is 0
+        b, c, d = struct.unpack_from("<3f", raw, 256)
+        off = np.array(struct.unpack_from("<3f", raw, 268), dtype=np.float64)
+        a2 = 1.0 - (b * b + c * c + d * d)
+        a = np.sqrt(a2) if a2 > 1e-7 else 0.0
+        if a2 <= 1e-7:
+            nrm = 1.0 / np.sqrt(b * b + c * c + d * d)
+            b, c, d = b * nrm, c * nrm, d * nrm
+        R = np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                      [2 * (b * c + a * d), a * a + c * c - b * b - d * d, 2 * (c * d - a * b)],
+                      [2 * (b * d - a * c), 2 * (c * d + a * b), a * a + d * d - b * b - c * c]], dtype=np.float64)
+        if pixdim[0] < 0:
+            R[:, 2] = -R[:, 2]
+        D = lps2ras @ R
+        origin = lps2ras @ off
     else:
         D = np.eye(3)
         origin = np.zeros(3)

@@ -115,9 +115,11 @@ class CineTrainer:
     def predict_preprocessed_data_return_seg_and_softmax_flow(self, unlabeled, target=None, target_mask=None, processor=None,
                                                               do_mirroring=True, mirror_axes=None, use_sliding_window=True, step_size=0.5,
                                                               use_gaussian=True, pad_border_mode="constant", pad_kwargs=None,
-                                                              all_in_gpu=False, verbose=True, mixed_precision=True, centroid=None):
+                                                              all_in_gpu=False, verbose=True, mixed_precision=True, centroid=None, return_crop=False):
         """unlabeled [T,1,Z,Y,X] (numpy) -> (seg [T,Z,Y,X], softmax [T,K,Z,Y,X], flow [T,2,Z,Y,X], registered [T,1,Z,Y,X],
-        raw [T,3,Z,crop,crop]).  target: optional ED label volume [Z,Y,X]."""
+        raw [T,3,Z,crop,crop]).  target: optional ED label volume [Z,Y,X].  centroid: (x, y) of the heart in the patch, or None (patch
+        centre).  return_crop=True appends the crop-space results the voxelmorph_saver layout stores: dict(softmax [T,K,Z,c,c],
+        flow [T,2,Z,c,c], registered [T,Z,c,c], padding_need [4,Z], size_before [Y,X,Z])."""
         processor = processor or self.processor
         mirror_axes = self.data_aug_params["mirror_axes"] if mirror_axes is None else mirror_axes
         T, _, Z, Y, X = unlabeled.shape
@@ -157,7 +159,13 @@ class CineTrainer:
         reg = place(out["registered"].float())[:, None]                                # [T,1,Z,Y,X]
         seg = ops.argmax_channels(softmax.reshape(T, self.num_classes, -1).contiguous()).view(T, Z, Y, X)
         raw = torch.cat([frames.permute(0, 2, 1, 3, 4), out["flow"].permute(0, 2, 1, 3, 4)], 1)
-        return seg.cpu().numpy(), softmax.cpu().numpy(), flow.cpu().numpy(), reg.cpu().numpy(), raw.cpu().numpy()
+        res = (seg.cpu().numpy(), softmax.cpu().numpy(), flow.cpu().numpy(), reg.cpu().numpy(), raw.cpu().numpy())
+        if return_crop:
+            crop_out = {"softmax": out["softmax"].permute(0, 2, 1, 3, 4).contiguous().cpu().numpy(),
+                        "flow": out["flow"].permute(0, 2, 1, 3, 4).contiguous().cpu().numpy(), "registered": out["registered"].cpu().numpy(),
+                        "padding_need": np.repeat(np.asarray(pad_need, dtype=np.int64)[:, None], Z, axis=1), "size_before": [int(Y), int(X), int(Z)]}
+            return res + (crop_out,)
+        return res
 
 
 def load_model_and_checkpoint_files(folder, folds=None, mixed_precision=None, checkpoint_name="model_final_checkpoint", device=None):
@@ -353,17 +361,42 @@ def put_ed_first(current_list_of_lists, current_output_files, csv_filepath):
     return [list(current_list_of_lists[i]) for i in order], [current_output_files[i] for i in order]
 
 
+_VOXELMORPH_RAW = None
+
+
+def set_voxelmorph_raw(pred_path, pkl_path=None):
+    """Switch on (pred_path given) or off (None) the additional `<pred_path>/Raw/{Registered,Segmentation,Flow}/<patient>/` +
+    `<pkl_path>/<case>.pkl` output of predict_flow -- the crop-space layout voxelmorph_saver_* post-processes.  A module-level switch, so
+    that predict_from_folder / predict_cases keep the reference's argument lists; pkl_path defaults to <pred_path>/pkl."""
+    global _VOXELMORPH_RAW
+    _VOXELMORPH_RAW = None if pred_path is None else (pred_path, pkl_path or join(pred_path, "pkl"))
+
+
 def predict_flow(d, trainer, output_filenames, property_list, do_tta, mixed_precision, params, interpolation_order, force_separate_z,
                  interpolation_order_z, all_in_gpu, step_size, save_npz, disable_postprocessing, model, pool):
     """predict.py:1008-1162 for one patient: `d[t]` = preprocessed frame t (ED first), all frames form the cine sequence.
-    Writes <patient>/{Segmentation,Flow,Registered}/<case>; returns the three path lists."""
+    Writes <patient>/{Segmentation,Flow,Registered}/<case>; returns the three path lists.
+    After set_voxelmorph_raw(pred_path, pkl_path) the crop-space predictions are additionally written as `<pred_path>/Raw/...` +
+    `<pkl_path>/<case>.pkl`, the input layout of voxelmorph_saver_* (cineflow.voxelmorph_saver)."""
+    voxelmorph_raw = _VOXELMORPH_RAW
     unlabeled = np.stack(d) + 1e-8                                               # predict.py:1025
     print("predicting", output_filenames)
-    seg, softmax, flow, registered, _raw = trainer.predict_preprocessed_data_return_seg_and_softmax_flow(
+    seg, softmax, flow, registered, _raw, crop_out = trainer.predict_preprocessed_data_return_seg_and_softmax_flow(
         unlabeled=unlabeled, target=None, target_mask=None, processor=trainer.processor, do_mirroring=do_tta,
         mirror_axes=trainer.data_aug_params["mirror_axes"], use_sliding_window=True, step_size=step_size, use_gaussian=True,
-        all_in_gpu=all_in_gpu, mixed_precision=mixed_precision, verbose=False)
+        all_in_gpu=all_in_gpu, mixed_precision=mixed_precision, verbose=False, return_crop=True)
     assert len(softmax) == len(flow) == len(registered)
+    if voxelmorph_raw is not None:
+        from .voxelmorph_saver import write_raw
+        patient = os.path.basename(os.path.dirname(os.path.abspath(output_filenames[0])))
+        write_raw(voxelmorph_raw[0], voxelmorph_raw[1], patient, [os.path.basename(o)[:-7] for o in output_filenames], crop_out["softmax"],
+                  crop_out["flow"], crop_out["registered"], property_list, crop_out["padding_need"], crop_out["size_before"], ed_position=0)
+    # back to the axis order of the files (predict.py:1084-1089): preprocessing applied plans['transpose_forward']
+    if trainer.plans.get("transpose_forward") is not None:
+        tb = [0] + [i + 1 for i in trainer.plans.get("transpose_backward")]
+        softmax = [np.ascontiguousarray(x.transpose(tb)) for x in softmax]
+        flow = [np.ascontiguousarray(x.transpose(tb)) for x in flow]
+        registered = [np.ascontiguousarray(x.transpose(tb)) for x in registered]
     seg_paths, flow_paths, reg_paths, jobs = [], [], [], []
     for t in range(len(softmax)):
         seg_path, flow_path, reg_path = (_subfolder_path(output_filenames[t], s_) for s_ in ("Segmentation", "Flow", "Registered"))
@@ -476,7 +509,8 @@ def predict_from_folder(model, input_folder, output_folder, folds, save_npz, num
                         overwrite_all_in_gpu=None, step_size=0.5, checkpoint_name="model_final_checkpoint",
                         segmentation_export_kwargs=None, disable_postprocessing=False):
     """predict.py:665-780.  Patients are sharded `patients[part_id::num_parts]` (one process per GPU); every patient of
-    the shard is processed."""
+    the shard is processed.  (set_voxelmorph_raw / the CLI's --voxelmorph_raw additionally produce the voxelmorph_saver input tree;
+    the argument list itself is the reference's, name for name.)"""
     os.makedirs(output_folder, exist_ok=True)
     assert os.path.isfile(join(model, "plans.json")), "Folder with saved model weights must contain a plans.json file"
     shutil.copy(join(model, "plans.json"), output_folder)
@@ -529,12 +563,17 @@ def main(argv=None):
     parser.add_argument("--step_size", type=float, default=0.5, required=False)
     parser.add_argument("--disable_mixed_precision", default=False, action="store_true", required=False)
     parser.add_argument("-chk", default="model_final_checkpoint", required=False)
+    parser.add_argument("--voxelmorph_raw", default=None, required=False, help="also write <dir>/Raw/{Registered,Segmentation,Flow}/<patient>/ "
+                        "(crop-space predictions, the input of voxelmorph_saver_*)")
+    parser.add_argument("--voxelmorph_pkl", default=None, required=False, help="folder for the per-file .pkl properties (default <voxelmorph_raw>/pkl)")
     a = parser.parse_args(argv)
     folds = a.folds if a.folds != "None" and a.folds != ["None"] else None
     if isinstance(folds, list):
         folds = [int(i) if i != "all" else i for i in folds]
     all_in_gpu = None if a.all_in_gpu == "None" else a.all_in_gpu == "True"
     tta = bool(a.tta) and not a.disable_tta
+    if a.voxelmorph_raw is not None:
+        set_voxelmorph_raw(a.voxelmorph_raw, a.voxelmorph_pkl)
     return predict_from_folder(a.model_output_folder, a.input_folder, a.output_folder, folds, a.save_npz, a.num_threads_preprocessing,
                                a.num_threads_nifti_save, None, a.part_id, a.num_parts, tta, mixed_precision=not a.disable_mixed_precision,
                                overwrite_existing=bool(a.overwrite_existing), mode=a.mode, overwrite_all_in_gpu=all_in_gpu,

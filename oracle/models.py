@@ -947,3 +947,70 @@ class Processor:
     def uncrop_no_registration(self, output, padding_need):
         assert len(output) == len(padding_need)
         return torch.stack([F.pad(output[b], pad=tuple(padding_need[b].tolist())) for b in range(len(output))], 0)
+
+
+# ----------------------------------------------------------------------------- per-slice flow wrapper (row a21)
+def pad_nd_image(image, new_shape, mode="constant", kwargs=None, return_slicer=False):
+    """batchgenerators pad_nd_image (un-vendored, parity unpinned; call site SegFlowGaussian.py:3310): pad the trailing
+    len(new_shape) axes to max(new, old), below = diff // 2, above = diff // 2 + diff % 2."""
+    if kwargs is None:
+        kwargs = {"constant_values": 0}
+    old = np.array(image.shape[-len(new_shape):])
+    new = np.array([max(n, o) for n, o in zip(new_shape, old)])
+    diff = new - old
+    below, above = diff // 2, diff // 2 + diff % 2
+    pad_list = [[0, 0]] * (image.ndim - len(new_shape)) + [list(i) for i in zip(below, above)]
+    res = np.pad(image, pad_list, mode, **kwargs) if diff.any() else image
+    if not return_slicer:
+        return res
+    pad_arr = np.array(pad_list)
+    pad_arr[:, 1] = np.array(res.shape) - pad_arr[:, 1]
+    return res, [slice(*i) for i in pad_arr]
+
+
+def predict_2d_tiled_flow(flow_net, seg_net, unlabeled, target, processor, mean_centroid, patch_size, do_mirroring=True, mirror_axes=(0, 1),
+                          num_classes=4):
+    """One slice through SegFlowGaussian._internal_predict_2D_2Dconv_tiled_flow (SegFlowGaussian.py:3294-3533) and
+    _internal_maybe_mirror_and_pred_2D (:3075-3245), with the two substitutions the build documents: the
+    segmentation comes from the 2-D U-Net under flip TTA (forward has no 'seg' output) and the heart centroid is an argument (the
+    reference computes it with the cropping network, processor.py:232-237).
+
+    unlabeled [T, 1, X, Y] (numpy, one slice over time), target [X, Y] label map of frame 0 or None (then frame 0's own argmax is
+    propagated), mean_centroid (x, y) in the centre-cropped patch.  Returns (seg [T,X,Y], softmax [T,K,X,Y], flow [T,2,X,Y],
+    registered [T,1,X,Y]) as float32 / int64 numpy arrays, cut back to the input size."""
+    from . import ops as OO
+    T = unlabeled.shape[0]
+    data, slicer = pad_nd_image(unlabeled, patch_size, "constant", {"constant_values": 0}, True)                 # :3310
+    H, W = data.shape[-2:]
+    y1, y2 = int((H / 2) - (patch_size[0] / 2)), int((H / 2) + (patch_size[0] / 2))                             # :3391-3394
+    x1, x2 = int((W / 2) - (patch_size[1] / 2)), int((W / 2) + (patch_size[1] / 2))
+    x_in = torch.from_numpy(np.ascontiguousarray(data[:, :, y1:y2, x1:x2])).float()                             # [T,1,P,P]
+    cropped, padding_need = processor.crop_and_pad(x_in, mean_centroid)                                          # :3101
+    cropped = OO.normalize_intensity(cropped.clone())                                                            # :3108 (whole [T,1,h,w] block)
+    cs = processor.crop_size
+    with torch.no_grad():
+        probs = mirror_and_predict_2d(seg_net, cropped, mirror_axes, do_mirroring)                               # [T,K,h,w]
+        flow = torch.zeros(T, 2, cs, cs)
+        idx = torch.arange(1, T)
+        c1, c2 = (list(torch.chunk(idx, 2)) + [idx[:0]])[:2] if T > 1 else (idx, idx)
+        for order in (torch.cat([torch.tensor([0]), c1]), torch.cat([torch.tensor([0]), torch.flip(c2, dims=[0])])):  # :3120-3127
+            if len(order) > 1:
+                bf = flow_net(cropped[order][:, None])["backward_flow"]                                          # [n-1,1,2,h,w]
+                for j, t in enumerate(order[1:].tolist()):
+                    flow[t] = bf[j, 0]
+        if target is not None:
+            tp = pad_nd_image(np.asarray(target)[None, None], patch_size, "constant", {"constant_values": 0}, False)
+            lab = processor.crop_and_pad(torch.from_numpy(np.ascontiguousarray(tp[:, :, y1:y2, x1:x2])).float(), mean_centroid)[0]
+        else:
+            lab = probs[:1].argmax(1, keepdim=True).float()
+        registered = OO.warp_labels(flow[:, None], lab)[:, 0].float()                                           # :3427 -> [T,1,h,w]
+    pn = padding_need[None]
+
+    def place(t):                                                                                                # :3450-3467 + slicer
+        full = processor.uncrop_no_registration(t[None], pn)[0]
+        canvas = torch.zeros(tuple(full.shape[:-2]) + (H, W), dtype=full.dtype)
+        canvas[..., y1:y2, x1:x2] += full
+        return canvas[..., slicer[-2], slicer[-1]].numpy()
+
+    softmax, flow_f, reg_f = place(probs), place(flow), place(registered)
+    return softmax.argmax(1), softmax, flow_f, reg_f

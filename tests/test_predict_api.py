@@ -200,7 +200,10 @@ def test_predict_from_folder_end_to_end(dev, tmp_path):
             assert f["flow"].shape == (Y, X, Z, 2) and np.allclose(f["spacing"], (1.5, 1.5, 8.0))
             assert np.allclose(pr["itk_spacing"], (1.5, 1.5, 8.0))
             sm = np.load(str(out / pat / "Segmentation" / (case + ".npz")))["softmax"]
-            assert sm.shape == (4, Z, Y, X) and np.array_equal(sm.astype(np.float32).argmax(0) == s, np.ones_like(s, bool)) or True
+            # the resampled-softmax npz is stored as float16 (segmentation_export.py:132): its argmax is the written label map except at
+            # ties the rounding creates
+            assert sm.shape == (4, Z, Y, X) and sm.dtype == np.float16
+            assert float((sm.astype(np.float32).argmax(0) == s).mean()) >= 0.999
         # the ED frame has zero flow and its registered labels equal its own segmentation
         ed = 1 if pat == "patient002" else 0
         case = "%s_frame%02d" % (pat, ed)
@@ -245,3 +248,210 @@ def test_predict_from_folder_end_to_end(dev, tmp_path):
     for name in ("predict_flow", "predict_non_flow", "predict_cases_fast", "predict_cases_fastest", "put_ed_first", "get_ed_es_indices",
                  "load_remove_save", "load_postprocessing"):
         assert callable(getattr(P, name))
+
+
+# ------------------------------------------------------------------------------------------------ voxelmorph_saver layout
+def _fake_patient(T, K, D, c, seed):
+    rng = np.random.default_rng(seed)
+    soft = rng.random((T, K, D, c, c)).astype(np.float32)
+    soft /= soft.sum(1, keepdims=True)
+    flow = rng.normal(size=(T, 2, D, c, c)).astype(np.float32)
+    flow[0] = 0
+    reg = rng.integers(0, K, size=(T, D, c, c)).astype(np.uint8)
+    return soft, flow, reg
+
+
+def test_resize_with_pad_or_crop_centre_rule():
+    """monai's ResizeWithPadOrCrop: symmetric pad with the smaller half in front, centre crop starting at n // 2 - t // 2"""
+    from cineflow.voxelmorph_saver import resize_with_pad_or_crop
+    a = np.arange(2 * 5 * 6 * 3, dtype=np.float32).reshape(2, 5, 6, 3)
+    out = resize_with_pad_or_crop(a, [8, 4, 3])            # pad 5 -> 8 (1 before, 2 after), crop 6 -> 4 (start 1), keep 3
+    assert out.shape == (2, 8, 4, 3)
+    assert np.array_equal(out[:, 1:6], a[:, :, 1:5]) and out[:, 0].max() == 0 and out[:, 6:].max() == 0
+    out = resize_with_pad_or_crop(a, [3, 7, 3])            # crop 5 -> 3 (start 1), pad 6 -> 7 (0 before, 1 after)
+    assert np.array_equal(out[:, :, :6], a[:, 1:4]) and out[:, :, 6].max() == 0
+    assert resize_with_pad_or_crop(a, [5, 6, 3]) is not None and np.array_equal(resize_with_pad_or_crop(a, [5, 6, 3]), a)
+
+
+def test_voxelmorph_raw_layout_is_what_the_reference_scripts_glob(tmp_path):
+    """write_raw produces the tree voxelmorph_saver_Lib.py:373-384 globs and the pickle keys it reads at :190-196 (plain pickle.load)."""
+    import pickle
+    from glob import glob
+    from cineflow.voxelmorph_saver import write_raw
+    from cineflow.nifti import read_nifti
+    T, K, D, c = 4, 4, 3, 16
+    soft, flow, reg = _fake_patient(T, K, D, c, 1)
+    names = ["patient007_frame%02d" % (t + 1) for t in range(T)]
+    props = [{"original_spacing": [8.0, 1.5, 1.5], "size_after_cropping": [D, 20, 22], "itk_spacing": (1.5, 1.5, 8.0)} for _ in range(T)]
+    pad = np.array([[2, 3, 1], [2, 1, 3], [4, 4, 4], [0, 0, 0]])
+    pred, pkl = str(tmp_path / "pred"), str(tmp_path / "pkl")
+    write_raw(pred, pkl, "patient007", names, soft, flow, reg, props, pad, [20, 22, D], ed_position=0)
+    pred_path_list_registered = sorted(glob(os.path.join(pred, "Raw", "Registered", "patient007", "*.gz")))
+    pred_path_list_seg = sorted(glob(os.path.join(pred, "Raw", "Segmentation", "patient007", "*.npz")))
+    pred_path_list_flow = sorted(glob(os.path.join(pred, "Raw", "Flow", "patient007", "*.npz")))
+    reg_names = [os.path.basename(x)[:-7] for x in pred_path_list_registered]
+    seg_ed = [x for x in pred_path_list_seg if os.path.basename(x)[:-4] not in reg_names]
+    assert len(pred_path_list_registered) == len(pred_path_list_flow) == T - 1 and len(pred_path_list_seg) == T
+    assert [os.path.basename(x) for x in seg_ed] == ["patient007_frame01.npz"]          # the ED frame has a segmentation only
+    for t in range(1, T):
+        with open(os.path.join(pkl, names[t] + ".pkl"), "rb") as f:     # written by this test run (plain values)
+            p = pickle.load(f)
+        assert np.array_equal(p["padding_need"], pad) and p["padding_need"].shape == (4, D) and p["voxelmorph_size_before"] == [20, 22, D]
+        assert p["original_spacing"] == [8.0, 1.5, 1.5]
+        assert np.load(pred_path_list_flow[t - 1])["flow"].shape == (c, c, D, 2)
+        assert np.load(os.path.join(pred, "Raw", "Segmentation", "patient007", names[t] + ".npz"))["seg"].shape == (K, c, c, D)
+        arr, _ = read_nifti(pred_path_list_registered[t - 1])
+        assert np.array_equal(arr.transpose(2, 1, 0), reg[t].transpose(1, 2, 0))        # nibabel view [H, W, D]
+
+
+@pytest.mark.gpu
+def test_voxelmorph_saver_postprocess_matches_direct_export(dev, tmp_path):
+    """set_voxelmorph_raw + predict_from_folder write Raw/ + pkl; cineflow.voxelmorph_saver.run turns them into
+    Postprocessed/{Flow,Registered,Segmentation}/<patient>/ + temp_allClasses/.  Both routes apply the same un-crop / centre / resample /
+    crop-box chain, so the saver's files must equal the files predict_from_folder wrote directly; then the downstream scripts' globs
+    (compute_metrics.py:51-56, compute_jacobian.py:128-139) are replayed on the tree."""
+    from glob import glob
+    from cineflow import predict as P
+    from cineflow import voxelmorph_saver as VS
+    from cineflow.models import SegFlowGaussian, Generic_UNet
+    from cineflow.nifti import read_nifti, write_nifti
+    from cineflow.weights import seeded_state_dict
+    from oracle import ops as OO
+    red = dict(in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=32, bottleneck_heads=4, dim_feedforward=48)
+    plans = P.default_plans(image_size=96, crop_size=64, flow_variant="video", seg_base=8, seg_pool=3, reduced=red)   # a real crop: 64 of 96
+    seg = Generic_UNet(1, 8, 4, 3)
+    flow = SegFlowGaussian(image_size=64, motion_appearance=False, **red)
+    sd_s = seeded_state_dict({k: v for k, v in seg.state_shapes().items()}, 10)
+    sd_f = seeded_state_dict({k: v for k, v in flow.state_shapes().items() if not k.endswith("grid")}, 11)
+    model = str(tmp_path / "model")
+    P.save_model_folder(model, seg, flow, plans, fold=0, seg_sd=sd_s, flow_sd=sd_f)
+    inp, out, pred, pkl = tmp_path / "in", tmp_path / "out", str(tmp_path / "pred"), str(tmp_path / "pkl")
+    g = torch.Generator().manual_seed(6)
+    T, Z, Y, X = 4, 3, 90, 104           # one axis below the 96 patch (padded), one above (centre cropped)
+    (inp / "patient003").mkdir(parents=True)
+    for t in range(T):
+        vol = torch.randn(Z, Y, X, generator=g).numpy().astype(np.float32) * 40 + 100
+        write_nifti(str(inp / "patient003" / ("patient003_frame%02d_0000.nii.gz" % t)), vol, (1.5, 1.5, 8.0), (0, 0, 0))
+    P.set_voxelmorph_raw(pred, pkl)
+    try:
+        P.predict_from_folder(model, str(inp), str(out), [0], False, 1, 2, None, 0, 1, True)
+    finally:
+        P.set_voxelmorph_raw(None)
+    post = VS.run(pred, pkl, plans, image_size=96, crop_size=64)
+    assert post == os.path.join(pred, "Postprocessed")
+    for t in range(T):
+        case = "patient003_frame%02d" % t
+        s_direct, _ = read_nifti(str(out / "patient003" / "Segmentation" / (case + ".nii.gz")))
+        s_saver, pr = read_nifti(os.path.join(post, "Segmentation", "patient003", case + ".nii.gz"))
+        assert np.array_equal(s_direct, s_saver) and np.allclose(pr["itk_spacing"], (1.5, 1.5, 8.0))
+        if t == 0:
+            assert not os.path.exists(os.path.join(post, "Registered", "patient003", case + ".nii.gz"))     # ED: segmentation only
+            continue
+        r_direct, _ = read_nifti(str(out / "patient003" / "Registered" / (case + ".nii.gz")))
+        r_saver, _ = read_nifti(os.path.join(post, "Registered", "patient003", case + ".nii.gz"))
+        assert np.array_equal(r_direct, r_saver)
+        f_direct = np.load(str(out / "patient003" / "Flow" / (case + ".npz")))["flow"]
+        f_saver = np.load(os.path.join(post, "Flow", "patient003", case + ".npz"))["flow"]
+        assert f_saver.shape == (Y, X, Z, 2) and np.array_equal(f_direct, f_saver)
+        # largest-component filter of determine_postprocessing_custom
+        pp, _ = read_nifti(os.path.join(post, "Registered", "patient003", "temp_allClasses", case + ".nii.gz"))
+        assert np.array_equal(pp, OO.remove_all_but_the_largest_connected_component(r_saver.copy(), [1, 2, 3], 1.5 * 1.5 * 8.0, None)[0])
+    # compute_metrics.py:54 and compute_jacobian.py:135-139 on the written tree
+    assert len(glob(os.path.join(post, "Registered", "patient003", "temp_allClasses", "*.gz"))) == T - 1
+    assert len(glob(os.path.join(post, "Segmentation", "patient003", "temp_allClasses", "*.gz"))) == T
+    video_flow = np.stack([np.load(p)["flow"] for p in sorted(glob(os.path.join(post, "Flow", "patient003", "*.npz")))], axis=0)
+    assert video_flow.shape == (T - 1, Y, X, Z, 2)
+    # flow-only mode (--no_seg)
+    post2 = VS.run(pred, pkl, plans, image_size=96, crop_size=64, no_seg=True)
+    assert len(glob(os.path.join(post2, "Registered", "patient003", "temp_allClasses", "*.gz"))) == T - 1
+    assert not glob(os.path.join(post2, "Segmentation", "patient003", "*.gz"))
+
+
+@pytest.mark.gpu
+def test_predict_undoes_transpose_forward(dev, tmp_path):
+    """plans with a non-identity transpose_forward (nnU-Net puts the anisotropic axis first): the export transposes softmax, flow and
+    propagated labels back with transpose_backward (predict.py:1084-1089), so the files have the input's axis order again."""
+    from cineflow import predict as P
+    from cineflow.models import SegFlowGaussian, Generic_UNet
+    from cineflow.nifti import read_nifti, write_nifti
+    from cineflow.weights import seeded_state_dict
+    red = dict(in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=32, bottleneck_heads=4, dim_feedforward=48)
+    plans = P.default_plans(image_size=64, crop_size=64, flow_variant="video", seg_base=8, seg_pool=3, reduced=red)
+    plans_t = dict(plans, transpose_forward=[0, 2, 1], transpose_backward=[0, 2, 1])
+    seg = Generic_UNet(1, 8, 4, 3)
+    flow = SegFlowGaussian(image_size=64, motion_appearance=False, **red)
+    sd_s = seeded_state_dict({k: v for k, v in seg.state_shapes().items()}, 10)
+    sd_f = seeded_state_dict({k: v for k, v in flow.state_shapes().items() if not k.endswith("grid")}, 11)
+    g = torch.Generator().manual_seed(8)
+    T, Z, Y, X = 3, 2, 48, 60
+    inp = tmp_path / "in"
+    (inp / "patient009").mkdir(parents=True)
+    vols = [torch.randn(Z, Y, X, generator=g).numpy().astype(np.float32) * 40 + 100 for _ in range(T)]
+    for t in range(T):
+        write_nifti(str(inp / "patient009" / ("patient009_frame%02d_0000.nii.gz" % t)), vols[t], (1.25, 1.5, 8.0), (0, 0, 0))
+    # the transposed plan on the original files == the identity plan on files whose in-plane axes are swapped, transposed back
+    inp_sw = tmp_path / "in_sw"
+    (inp_sw / "patient009").mkdir(parents=True)
+    for t in range(T):
+        write_nifti(str(inp_sw / "patient009" / ("patient009_frame%02d_0000.nii.gz" % t)), np.ascontiguousarray(vols[t].transpose(0, 2, 1)),
+                    (1.5, 1.25, 8.0), (0, 0, 0))
+    for name, pl in (("model_t", plans_t), ("model_i", plans)):
+        P.save_model_folder(str(tmp_path / name), seg, flow, pl, fold=0, seg_sd=sd_s, flow_sd=sd_f)
+    P.predict_from_folder(str(tmp_path / "model_t"), str(inp), str(tmp_path / "out_t"), [0], False, 1, 1, None, 0, 1, False)
+    P.predict_from_folder(str(tmp_path / "model_i"), str(inp_sw), str(tmp_path / "out_i"), [0], False, 1, 1, None, 0, 1, False)
+    for t in range(T):
+        case = "patient009_frame%02d" % t
+        s_t, pr = read_nifti(str(tmp_path / "out_t" / "patient009" / "Segmentation" / (case + ".nii.gz")))
+        s_i, _ = read_nifti(str(tmp_path / "out_i" / "patient009" / "Segmentation" / (case + ".nii.gz")))
+        assert s_t.shape == (Z, Y, X) and np.allclose(pr["itk_spacing"], (1.25, 1.5, 8.0))
+        assert np.array_equal(s_t, s_i.transpose(0, 2, 1))
+        r_t, _ = read_nifti(str(tmp_path / "out_t" / "patient009" / "Registered" / (case + ".nii.gz")))
+        r_i, _ = read_nifti(str(tmp_path / "out_i" / "patient009" / "Registered" / (case + ".nii.gz")))
+        assert np.array_equal(r_t, r_i.transpose(0, 2, 1))
+        f_t = np.load(str(tmp_path / "out_t" / "patient009" / "Flow" / (case + ".npz")))["flow"]
+        f_i = np.load(str(tmp_path / "out_i" / "patient009" / "Flow" / (case + ".npz")))["flow"]
+        # arrays are transposed, components are not swapped (as in the reference); the z-score of the transposed volume sums in another order
+        assert f_t.shape == (Y, X, Z, 2) and float(np.abs(f_t - f_i.transpose(1, 0, 2, 3)).max()) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ the per-slice flow wrapper (row a21)
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,centroid,with_target", [((80, 110), (25, 60), True),    # one axis padded, one centre cropped; window clamped at the left
+                                                         ((96, 96), (70, 40), False),   # patch sized; off-centre window (clamped right); ED argmax propagated
+                                                         ((120, 104), (47, 50), True)])  # both axes centre cropped; near-centre window
+def test_flow_wrapper_values_vs_oracle(dev, shape, centroid, with_target):
+    """trainer.predict_preprocessed_data_return_seg_and_softmax_flow against the oracle restatement of
+    _internal_predict_2D_2Dconv_tiled_flow (SegFlowGaussian.py:3294-3533): pad -> centre crop -> Processor crop around an off-centre
+    centroid -> NormalizeIntensity -> networks -> label warp -> un-crop -> placement -> un-pad, compared VALUE by value."""
+    from cineflow import predict as P
+    from cineflow.weights import seeded_state_dict, fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    red = dict(in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=32, bottleneck_heads=4, dim_feedforward=48)
+    plans = P.default_plans(image_size=96, crop_size=64, flow_variant="video", seg_base=8, seg_pool=3, reduced=red)
+    tr = P.CineTrainer(plans, dev)
+    sd_s = seeded_state_dict(tr.seg_net.state_shapes(), 10)
+    sd_f = seeded_state_dict({k: v for k, v in tr.flow_net.state_shapes().items() if not k.endswith("grid")}, 11)
+    tr.load_checkpoint_ram({"seg_state_dict": sd_s, "flow_state_dict": sd_f})
+    ofnet = fill_module_(OM.SegFlowGaussian(image_size=64, motion_appearance=False, **red), 11)
+    osnet = fill_module_(OM.GenericUNet2D(1, 8, 4, 3), 10)
+    g = torch.Generator().manual_seed(12)
+    T, Z = 5, 2
+    Y, X = shape
+    unl = (torch.randn(T, 1, Z, Y, X, generator=g) * 30 + 80).numpy().astype(np.float32)
+    target = (torch.rand(Z, Y, X, generator=g) * 4).floor().numpy().astype(np.uint8) if with_target else None
+    seg, softmax, flow, reg, _raw = tr.predict_preprocessed_data_return_seg_and_softmax_flow(unl, target=target, centroid=centroid)
+    assert seg.shape == (T, Z, Y, X) and softmax.shape == (T, 4, Z, Y, X) and flow.shape == (T, 2, Z, Y, X) and reg.shape == (T, 1, Z, Y, X)
+    oproc = OM.Processor(64, 96)
+    for z in range(Z):
+        oseg, osm, ofl, oreg = OM.predict_2d_tiled_flow(ofnet, osnet, unl[:, :, z], None if target is None else target[z], oproc, centroid, (96, 96))
+        assert float(np.abs(softmax[:, :, z] - osm).max()) <= 5e-5
+        assert OO.mean_epe(torch.from_numpy(flow[:, :, z]), torch.from_numpy(ofl)) <= 1e-4
+        assert float((seg[:, z] == oseg).mean()) >= 0.9995
+        for k in range(4):
+            d = OO.dice(reg[:, 0, z], oreg[:, 0], k)
+            assert np.isnan(d) or abs(d - 1.0) <= 1e-3
+        # zeros outside the un-cropped window, something inside it
+        win = oproc.adjust_cropping_window(centroid)["crop_indices"]
+        assert float(np.abs(ofl).max()) > 0
+    assert float(np.abs(flow[0]).max()) == 0.0          # ED frame: no flow
