@@ -93,6 +93,8 @@ SIGNATURES = {
     "cf_spatial_gradient3d": [P, P, L, I, I, I, P],
     "cf_slab_abs_sum": [P, I, I, I, L, P, P],
     "cf_ssim_map": [P, P, I, I, I, DBL, DBL, DBL, P, P],
+    "cf_frame_boxes": [P, I, P, I, I, I, P],
+    "cf_sample_points_2d": [P, P, P, I, I, I, I, I, P],
     "cf_profile_enable": [I],
     "cf_profile_reset": [],
     "cf_profile_read": [I, P, P, P],

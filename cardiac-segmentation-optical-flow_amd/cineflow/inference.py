@@ -179,12 +179,52 @@ def predict_3D_3Dconv_tiled(net, x, patch_size, step_size=0.5, do_mirroring=True
 
 # ------------------------------------------------------------------------------------------------ Processor
 class Processor:
-    """Crop / un-crop arithmetic of nnunet/training/network_training/processor.py:109-138, :178-186, :223-230.
-    The centroid comes from the caller (the reference gets it from a separate 2-class cropping network,
-    processor.py:140-160, which is outside this path -- SURVEY.md row a20)."""
+    """nnunet/training/network_training/processor.py: the crop / un-crop arithmetic (:109-138, :178-186, :223-230) and the heart
+    centroid (:140-160 get_mean_centroid, :162-176 discretize, :232-237 preprocess_no_registration).
 
-    def __init__(self, crop_size, image_size):
-        self.crop_size, self.image_size = crop_size, image_size
+    cropping_network: any callable mapping a device batch [N,1,H,W] to {'pred': logits [N,K,H,W]} (the reference builds a 2-class
+    MTLmodel from adversarial_acdc.yaml, voxelmorph_saver_Lib.py:328-335; `CroppingNet` below wraps any cineflow network).  Without
+    one the centroid must be passed by the caller (or defaults to the image centre)."""
+
+    def __init__(self, crop_size, image_size, cropping_network=None):
+        self.crop_size, self.image_size, self.cropping_network = crop_size, image_size, cropping_network
+
+    # -- processor.py:162-176
+    def discretize(self, data):
+        """data [T,1,H,W] (device) -> label maps uint8 [T,H,W]: per frame NormalizeIntensity, network, softmax, argmax; an all-zero
+        frame gives an all-zero map (the network is not consulted for it).  All frames go through the network as one batch."""
+        T, one, H, W = data.shape
+        assert one == 1
+        x = data.contiguous().clone()
+        nonempty = (ops.frame_boxes(x.view(T, H, W))[:, 0] >= 0)                  # frames with a non-zero pixel
+        flat = x.view(T, 1, H * W)
+        ops.group_norm(flat, None, None, 1, eps=0.0, out=flat)                    # per-frame z-score (population std), in place
+        logits = self.cropping_network(x)["pred"]
+        lab = ops.argmax_channels(logits.contiguous())                            # softmax is monotone: argmax of the logits
+        lab[~nonempty] = 0
+        return lab
+
+    # -- processor.py:140-160
+    def get_mean_centroid(self, data):
+        """label maps [T,H,W] (device) -> (x, y) int: mean over the frames of the bounding-box centre of the non-zero pixels; a frame
+        without any contributes (H/2, W/2) -- in that order, as the reference writes it."""
+        T, H, W = data.shape
+        boxes = ops.frame_boxes(data.contiguous()).cpu().to(torch.float32)       # [T,4] x1, y1, x2, y2 (tiny: the arithmetic below is the reference's)
+        cen = []
+        for t in range(T):
+            if boxes[t, 0] < 0:
+                cen.append(torch.tensor([H / 2, W / 2]).view(1, 2))
+            else:
+                x = boxes[t, 0] + ((boxes[t, 2] - boxes[t, 0]) / 2)
+                y = boxes[t, 1] + ((boxes[t, 3] - boxes[t, 1]) / 2)
+                cen.append(torch.stack([x, y], dim=-1).view(1, 2))
+        return torch.cat(cen, dim=0).mean(0).int()
+
+    # -- processor.py:232-237
+    def preprocess_no_registration(self, data):
+        """data [T,1,H,W] -> (mean_centroid (x, y) int tensor, label maps [T,H,W])"""
+        temp_volume = self.discretize(data)
+        return self.get_mean_centroid(temp_volume), temp_volume
 
     def adjust_cropping_window(self, centroid):
         half = self.crop_size // 2
@@ -216,6 +256,17 @@ class Processor:
         left, right, top, bottom = (int(v) for v in padding_need)
         h, w = output.shape[-2:]
         return ops.pad2d(output, top, left, h + top + bottom, w + left + right)
+
+
+class CroppingNet:
+    """Adapter giving a cineflow network (e.g. Generic_UNet(1, base, 2, pools)) the interface Processor.discretize expects from the
+    reference's cropping network: net(x)['pred'] = logits."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def __call__(self, x):
+        return {"pred": self.net(x)}
 
 
 # ------------------------------------------------------------------------------------------------ joint seg + flow

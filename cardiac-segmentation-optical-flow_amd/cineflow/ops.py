@@ -559,6 +559,26 @@ def argmax_channels(x):
     return out
 
 
+def frame_boxes(x):
+    """x [N,H,W] uint8 or float32 on the device -> int32 [N,4] = (x1, y1, x2, y2) of the non-zero pixels per frame, -1 for empty frames
+    (torchvision.ops.masks_to_boxes as processor.py:140-160 uses it)."""
+    assert x.is_cuda and x.dim() == 3 and x.is_contiguous() and x.dtype in (torch.uint8, torch.float32)
+    N, H, W = x.shape
+    boxes = torch.empty((N, 4), dtype=torch.int32, device=x.device)
+    check(lib().cf_frame_boxes(x.data_ptr(), int(x.dtype == torch.float32), boxes.data_ptr(), N, H, W, _stream()), "cf_frame_boxes")
+    return boxes
+
+
+def sample_points(field, pts):
+    """SpatialTransformerContour (integration.py:5-34): field [B,C,H,W], pts [B,2,P] (channel 0 along W, channel 1 along H) -> [B,C,P]."""
+    B, C, H, W = field.shape
+    assert pts.shape[0] == B and pts.shape[1] == 2
+    P_ = pts.shape[2]
+    out = torch.empty((B, C, P_), dtype=torch.float32, device=field.device)
+    check(lib().cf_sample_points_2d(_f32(field), _f32(pts), _f32(out), B, C, H, W, P_, _stream()), "cf_sample_points_2d")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ export post-processing
 def resize3d(src, new_shape, linear=(1, 1, 1)):
     """src [N,X,Y,Z] float32 -> [N,*new_shape]; per axis linear (order 1) or nearest (order 0); skimage 'edge' semantics."""

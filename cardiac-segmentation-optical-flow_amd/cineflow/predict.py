@@ -35,14 +35,16 @@ join = os.path.join
 
 
 # ------------------------------------------------------------------------------------------------ model folder
-def save_model_folder(folder, seg_net, flow_net, plans, fold=0, checkpoint_name="model_final_checkpoint", seg_sd=None, flow_sd=None):
+def save_model_folder(folder, seg_net, flow_net, plans, fold=0, checkpoint_name="model_final_checkpoint", seg_sd=None, flow_sd=None, crop_sd=None):
     """Write `<folder>/plans.json` and `<folder>/fold_<fold>/<checkpoint_name>.model` (state dicts keyed by the
-    reference's parameter names).  `seg_sd` / `flow_sd`: {name: tensor}."""
+    reference's parameter names).  `seg_sd` / `flow_sd` / `crop_sd` (the Processor's cropping network, plans['cropping_net']): {name: tensor}."""
     os.makedirs(join(folder, "fold_%d" % fold), exist_ok=True)
     with open(join(folder, "plans.json"), "w") as f:
         json.dump(plans, f, indent=1)
-    torch.save({"seg_state_dict": {k: v.cpu() for k, v in seg_sd.items()}, "flow_state_dict": {k: v.cpu() for k, v in flow_sd.items()}},
-               join(folder, "fold_%d" % fold, checkpoint_name + ".model"))
+    ck = {"seg_state_dict": {k: v.cpu() for k, v in seg_sd.items()}, "flow_state_dict": {k: v.cpu() for k, v in flow_sd.items()}}
+    if crop_sd is not None:
+        ck["crop_state_dict"] = {k: v.cpu() for k, v in crop_sd.items()}
+    torch.save(ck, join(folder, "fold_%d" % fold, checkpoint_name + ".model"))
 
 
 def default_plans(image_size=256, crop_size=None, flow_variant="video", seg_base=32, seg_pool=6, reduced=None):
@@ -63,6 +65,15 @@ class CineTrainer:
         self.data_aug_params = {"mirror_axes": tuple(plans["mirror_axes"])}
         self.patch_size = tuple(plans["patch_size"])
         self.processor = Processor(crop_size=plans["crop_size"], image_size=plans["patch_size"][0])
+        # the Processor's 2-class cropping network (processor.py:162-176).  The reference builds an MTLmodel from adversarial_acdc.yaml
+        # (voxelmorph_saver_Lib.py:328-335); plans['cropping_net'] = {'base_num_features', 'num_pool'} puts a 2-class Generic_UNet in its
+        # place (a documented stand-in: the centroid ARITHMETIC around it is the reference's, the network is not the same architecture)
+        self.crop_net = None
+        ck = plans.get("cropping_net")
+        if ck:
+            from .inference import CroppingNet
+            self.crop_net = Generic_UNet(1, ck["base_num_features"], 2, ck["num_pool"])
+            self.processor.cropping_network = CroppingNet(self.crop_net)
         sk = plans["seg_net"]
         self.seg_net = Generic_UNet(plans["num_modalities"], sk["base_num_features"], self.num_classes, sk["num_pool"])
         fk = plans["flow_net"]
@@ -75,6 +86,8 @@ class CineTrainer:
     def load_checkpoint_ram(self, params, train=False):
         self.seg_net.load_state_dict(params["seg_state_dict"], self.device)
         self.flow_net.load_state_dict(params["flow_state_dict"], self.device)
+        if self.crop_net is not None:
+            self.crop_net.load_state_dict(params["crop_state_dict"], self.device)
 
     # -- nnUNetTrainer.py:571-597 preprocess_patient(list_of_files) -> (data[C,Z,Y,X], seg, properties)
     def preprocess_patient(self, input_files):
@@ -132,24 +145,36 @@ class CineTrainer:
         dev = self.device
         patch = torch.from_numpy(np.ascontiguousarray(data[:, :, y1:y2, x1:x2])).to(dev, dtype=torch.float32)   # [T,Z,P,P]
         cs = processor.crop_size
-        cen = centroid if centroid is not None else (P[1] // 2, P[0] // 2)              # (x, y): image centre (see module docstring)
-        win = processor.adjust_cropping_window(cen)
-        cx0, cx1, cy0, cy1 = win["crop_indices"]
-        crop = ops.crop2d(patch, cy0, cx0, cs, cs)                                      # [T,Z,cs,cs]
-        for z in range(Z):                                                              # :3108 NormalizeIntensity on each slice's [T,h,w] block
-            blk = crop[:, z].contiguous()
-            normalize_intensity_(blk)
+        # one cropping window per slice (SegFlowGaussian.py:3099-3103 runs per slice): around the caller's centroid, else around the mean
+        # centroid of the cropping network's masks (processor.py:232-237), else around the patch centre
+        wins = []
+        for z in range(Z):
+            if centroid is not None:
+                cen = centroid
+            elif getattr(processor, "cropping_network", None) is not None:
+                cen = [int(v) for v in processor.preprocess_no_registration(patch[:, z].unsqueeze(1).contiguous())[0]]
+            else:
+                cen = (P[1] // 2, P[0] // 2)
+            wins.append(processor.adjust_cropping_window(cen))
+        crop = torch.empty((T, Z, cs, cs), dtype=torch.float32, device=dev)
+        for z in range(Z):
+            cx0, cx1, cy0, cy1 = wins[z]["crop_indices"]
+            blk = ops.crop2d(patch[:, z].contiguous(), cy0, cx0, cs, cs)               # [T,cs,cs]
+            normalize_intensity_(blk)                                                   # :3108 NormalizeIntensity on the slice's [T,h,w] block
             crop[:, z] = blk
         frames = crop.view(T, Z, 1, cs, cs)
         ed = None
         if target is not None:
             tp = pad_nd_image(np.asarray(target)[None], P, "constant", {"constant_values": 0}, False)[0]
-            ed = torch.from_numpy(np.ascontiguousarray(tp[:, y1:y2, x1:x2][:, cy0:cy1, cx0:cx1])).to(dev, dtype=torch.uint8)
+            tp = tp[:, y1:y2, x1:x2]
+            ed = torch.from_numpy(np.ascontiguousarray(np.stack([tp[z, wins[z]["crop_indices"][2]:wins[z]["crop_indices"][3],
+                                                                    wins[z]["crop_indices"][0]:wins[z]["crop_indices"][1]] for z in range(Z)]))).to(dev, dtype=torch.uint8)
         out = predict_cine_slices(self.flow_net, self.seg_net, frames, ed, do_mirroring, mirror_axes)
-        pad_need = win["padding_need"]
+        pad_need = np.stack([np.asarray(w["padding_need"], dtype=np.int64) for w in wins], axis=1)     # [4, Z]
 
-        def place(t):  # [..., cs, cs] -> [..., Y, X]: uncrop (processor.py:178-186), centre window, un-pad
-            full = processor.uncrop_no_registration(t, pad_need)
+        def place(t):  # [T, C?, Z, cs, cs] -> [..., Z, Y, X]: per-slice uncrop (processor.py:178-186), centre window, un-pad
+            zax = t.dim() - 3
+            full = torch.stack([processor.uncrop_no_registration(t.select(zax, z).contiguous(), pad_need[:, z]) for z in range(Z)], dim=zax)
             canvas = torch.zeros(tuple(full.shape[:-2]) + (Hp, Wp), dtype=full.dtype, device=dev)
             canvas[..., y1:y2, x1:x2] = full
             return canvas[..., slicer[-2], slicer[-1]]
@@ -163,7 +188,7 @@ class CineTrainer:
         if return_crop:
             crop_out = {"softmax": out["softmax"].permute(0, 2, 1, 3, 4).contiguous().cpu().numpy(),
                         "flow": out["flow"].permute(0, 2, 1, 3, 4).contiguous().cpu().numpy(), "registered": out["registered"].cpu().numpy(),
-                        "padding_need": np.repeat(np.asarray(pad_need, dtype=np.int64)[:, None], Z, axis=1), "size_before": [int(Y), int(X), int(Z)]}
+                        "padding_need": pad_need, "size_before": [int(Y), int(X), int(Z)]}
             return res + (crop_out,)
         return res
 

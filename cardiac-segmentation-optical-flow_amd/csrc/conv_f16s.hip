@@ -413,11 +413,13 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
                 }
                 // group q + 1's fragments must have landed before anyone reads them: vmcnt retires in order, so at the end of group 0 the
                 // patch loads issued after the DMAs (VEC: 4 per task) may stay in flight
-                if (VEC && grp == 0 && NGRP > 1) {
-                    if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VEC * 4) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (g.ablate != 5) {
+                    if (VEC && grp == 0 && NGRP > 1) {
+                        if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VEC * 4) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
                 }
                 if (g.ablate != 4 || grp == NGRP - 1) __syncthreads();
             }

@@ -320,3 +320,71 @@ extern "C" int cf_tile_accumulate_3d(const float* pred, const float* gauss, floa
     long total = (long)K * px * py * pz;
     LAUNCH_FLAT(tile_accumulate_3d_kernel, total, pred, gauss, agg, cnt, X, Y, Z, lx, ly, lz, px, py, pz, total);
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-frame bounding boxes of the non-zero pixels (torchvision.ops.masks_to_boxes as Processor.get_mean_centroid uses it,
+// processor.py:140-160) and bilinear sampling of a field at a list of points (SpatialTransformerContour, integration.py:5-34).
+namespace cf {
+
+template <typename T>
+__global__ void __launch_bounds__(256) frame_boxes_kernel(const T* __restrict__ x, int* __restrict__ boxes, int H, int W) {
+    __shared__ int red[4];   // x1, y1 (min), x2, y2 (max)
+    if (threadIdx.x < 4) red[threadIdx.x] = threadIdx.x < 2 ? INT_MAX : -1;
+    __syncthreads();
+    const T* f = x + (long)blockIdx.x * H * W;
+    int x1 = INT_MAX, y1 = INT_MAX, x2 = -1, y2 = -1;
+    for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
+        if (f[i] != (T)0) {
+            const int yy = i / W, xx = i - yy * W;
+            x1 = min(x1, xx); y1 = min(y1, yy); x2 = max(x2, xx); y2 = max(y2, yy);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        x1 = min(x1, __shfl_xor(x1, o, 64)); y1 = min(y1, __shfl_xor(y1, o, 64));
+        x2 = max(x2, __shfl_xor(x2, o, 64)); y2 = max(y2, __shfl_xor(y2, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&red[0], x1); atomicMin(&red[1], y1); atomicMax(&red[2], x2); atomicMax(&red[3], y2); }
+    __syncthreads();
+    if (threadIdx.x < 4) boxes[blockIdx.x * 4 + threadIdx.x] = red[2] < 0 ? -1 : red[threadIdx.x];
+}
+
+// out[b, c, p] = bilinear sample of field[b, c] at the point whose grid_sample coordinates are (gx, gy) = the normalised
+// (pts[b,0,p], pts[b,1,p]): 2 * (v / (size - 1) - 0.5) with size = W for channel 0 and H for channel 1 (the reference's shape[~i]),
+// align_corners = True, zeros outside -- every intermediate rounded as PyTorch rounds it.
+__global__ void __launch_bounds__(256) sample_points_kernel(const float* __restrict__ field, const float* __restrict__ pts, float* __restrict__ out,
+                                                           int B, int C, int H, int W, int P) {
+    const long total = (long)B * C * P;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(idx % P);
+        const long r = idx / P;
+        const int c = (int)(r % C), b = (int)(r / C);
+        const float px = pts[((long)b * 2 + 0) * P + p], py = pts[((long)b * 2 + 1) * P + p];
+        const float gx = __fmul_rn(2.0f, __fsub_rn(__fdiv_rn(px, (float)(W - 1)), 0.5f));
+        const float gy = __fmul_rn(2.0f, __fsub_rn(__fdiv_rn(py, (float)(H - 1)), 0.5f));
+        const float xs = __fmul_rn(__fdiv_rn(__fadd_rn(gx, 1.0f), 2.0f), (float)(W - 1));
+        const float ys = __fmul_rn(__fdiv_rn(__fadd_rn(gy, 1.0f), 2.0f), (float)(H - 1));
+        Taps t = make_taps(ys, xs, H, W);
+        out[idx] = sample_taps(field + ((long)b * C + c) * H * W, t, W);
+    }
+}
+
+}  // namespace cf
+
+extern "C" int cf_frame_boxes(const void* x, int is_float, int* boxes, int N, int H, int W, void* stream) {
+    CF_REQUIRE(x && boxes, "null pointer");
+    CF_REQUIRE(N > 0 && H > 0 && W > 0 && (long)H * W < (1L << 31), "bad shape N=%d H=%d W=%d", N, H, W);
+    if (is_float) hipLaunchKernelGGL(cf::frame_boxes_kernel<float>, dim3((unsigned)N), dim3(256), 0, cf::as_stream(stream), (const float*)x, boxes, H, W);
+    else hipLaunchKernelGGL(cf::frame_boxes_kernel<uint8_t>, dim3((unsigned)N), dim3(256), 0, cf::as_stream(stream), (const uint8_t*)x, boxes, H, W);
+    CF_CHECK_LAUNCH();
+    return CF_OK;
+}
+
+extern "C" int cf_sample_points_2d(const float* field, const float* pts, float* out, int B, int C, int H, int W, int P, void* stream) {
+    CF_REQUIRE(field && pts && out, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && H > 1 && W > 1 && P > 0, "bad shape");
+    const long total = (long)B * C * P;
+    hipLaunchKernelGGL(cf::sample_points_kernel, dim3(cf::flat_grid(total, 256)), dim3(256), 0, cf::as_stream(stream), field, pts, out, B, C, H, W, P);
+    CF_CHECK_LAUNCH();
+    return CF_OK;
+}

@@ -307,6 +307,14 @@ int cf_slab_abs_sum(const float* x, int C, int A, int S, long B, double* sums, v
  * cov_norm = NP / (NP - 1).  The mean over the interior (cf_region_stats on the cropped map) is the score. */
 int cf_ssim_map(const double* im1, const double* im2, int H, int W, int win, double C1, double C2, double cov_norm, double* S, void* stream);
 
+/* Processor.get_mean_centroid's masks_to_boxes (training/network_training/processor.py:140-160): per frame n of x [N][H][W]
+ * (uint8, or float32 when is_float) boxes[n] = {x1, y1, x2, y2} of the non-zero pixels, or {-1,-1,-1,-1} for an all-zero frame. */
+int cf_frame_boxes(const void* x, int is_float, int* boxes, int N, int H, int W, void* stream);
+/* SpatialTransformerContour.forward(new_locs, original) (network_architecture/integration.py:5-34) as get_strain.py calls it:
+ * out[b,c,p] = bilinear sample (align_corners, zeros outside) of field [B][C][H][W] at the contour point (pts[b,0,p], pts[b,1,p]) --
+ * channel 0 is normalised by W - 1 and used as grid x, channel 1 by H - 1 as grid y (the reference's shape[~i]). */
+int cf_sample_points_2d(const float* field, const float* pts, float* out, int B, int C, int H, int W, int P, void* stream);
+
 /* ---------------------------------------------------------------- measurement hooks (bench.py only; no reference analogue)
  * cf_profile_enable(n): pre-create n event pairs and time every conv / CorrVolume launch with a (start, stop) pair that
  * brackets exactly that kernel on its own stream (hipExtLaunchKernelGGL); 0 disables.  Kernel ids:

@@ -914,11 +914,58 @@ def predict_3d_tiled(net, x, patch_size, step_size=0.5, do_mirroring=True, mirro
 
 
 # ----------------------------------------------------------------------------- Processor crop arithmetic
-class Processor:
-    """nnunet/training/network_training/processor.py:109-138,178-186,223-230 (crop / uncrop arithmetic)."""
+def masks_to_boxes(masks):
+    """torchvision.ops.masks_to_boxes (torchvision absent -> restated from its documentation, parity unpinned): masks [N,H,W] ->
+    float [N,4] = (x1, y1, x2, y2), the extreme coordinates of the non-zero pixels."""
+    out = torch.zeros((masks.shape[0], 4), dtype=torch.float32)
+    for i, m in enumerate(masks):
+        y, x = torch.where(m != 0)
+        out[i] = torch.tensor([x.min(), y.min(), x.max(), y.max()], dtype=torch.float32)
+    return out
 
-    def __init__(self, crop_size, image_size):
-        self.crop_size, self.image_size = crop_size, image_size
+
+class Processor:
+    """nnunet/training/network_training/processor.py:109-138,178-186,223-230 (crop / uncrop arithmetic) and :140-176, :232-237
+    (discretize / get_mean_centroid / preprocess_no_registration)."""
+
+    def __init__(self, crop_size, image_size, cropping_network=None):
+        self.crop_size, self.image_size, self.cropping_network = crop_size, image_size, cropping_network
+
+    def discretize(self, data):
+        """processor.py:162-176: data [T,1,H,W] -> [T,H,W] int64"""
+        from . import ops as OO
+        out_list = []
+        for i in range(len(data)):
+            cur = data[i][None]
+            if torch.count_nonzero(cur) == 0:
+                soft = torch.zeros_like(cur)
+            else:
+                soft = torch.softmax(self.cropping_network(OO.normalize_intensity(cur))["pred"], dim=1)
+            out_list.append(torch.argmax(soft, dim=1).squeeze(0))
+        return torch.stack(out_list, dim=0)
+
+    def get_mean_centroid(self, data):
+        """processor.py:140-160"""
+        T, H, W = data.shape
+        data = data.clone()
+        data[data > 0] = 1
+        cen = []
+        for t in range(len(data)):
+            cur = data[t]
+            if torch.count_nonzero(cur) == 0:
+                c = torch.tensor([H / 2, W / 2]).view(1, 2)
+            else:
+                coords = masks_to_boxes(cur.unsqueeze(0))
+                x = coords[:, 0] + ((coords[:, 2] - coords[:, 0]) / 2)
+                y = coords[:, 1] + ((coords[:, 3] - coords[:, 1]) / 2)
+                c = torch.stack([x, y], dim=-1)
+            cen.append(c)
+        return torch.cat(cen, dim=0).mean(0).int()
+
+    def preprocess_no_registration(self, data):
+        """processor.py:232-237"""
+        temp_volume = self.discretize(data)
+        return self.get_mean_centroid(temp_volume), temp_volume
 
     def adjust_cropping_window(self, centroid):
         half = self.crop_size // 2

@@ -412,3 +412,42 @@ def test_generic_unet_bench_width_vs_oracle(dev):
     for k in range(4):
         d = OO.dice(a, b, k)
         assert np.isnan(d) or abs(d - 1.0) <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ Processor centroid path
+def test_processor_centroid_vs_oracle(dev):
+    """Processor.discretize / get_mean_centroid / preprocess_no_registration (processor.py:140-176, 232-237) with a 2-class network:
+    device path (batched frames, cf_frame_boxes) against the oracle's frame-by-frame restatement, empty frames included."""
+    from cineflow.inference import Processor, CroppingNet
+    from cineflow.models import Generic_UNet
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    net = load(Generic_UNet(1, 8, 2, 3), 51, dev)
+    onet = fill_module_(OM.GenericUNet2D(1, 8, 2, 3), 51)
+    proc = Processor(32, 64, CroppingNet(net))
+    oproc = OM.Processor(32, 64, lambda x: {"pred": onet(x)})
+    frames = smooth_cine(6, 1, 64, 21)[:, 0] * 40 + 90          # [T,1,64,64]
+    frames[2] = 0                                               # an all-zero frame: no network, empty mask
+    cen, lab = proc.preprocess_no_registration(frames.to(dev))
+    from oracle import ops as OO
+    with torch.no_grad():
+        ocen, olab = oproc.preprocess_no_registration(frames)
+        ologit = torch.stack([onet(OO.normalize_intensity(frames[t][None]))[0] for t in range(6) if t != 2])
+    # random weights leave the two logits nearly tied over smooth regions: the label maps must agree wherever the oracle's margin is
+    # above the 5e-5 logit tolerance, and the frame without signal is empty
+    sure = (ologit[:, 0] - ologit[:, 1]).abs() > 1e-3
+    keep = [t for t in range(6) if t != 2]
+    assert float(sure.float().mean()) > 0.5
+    assert bool((lab.cpu().long()[keep][sure] == olab[keep][sure]).all()) and int(lab[2].max()) == 0 and int(olab[2].max()) == 0
+    if float((lab.cpu().long() == olab).float().mean()) == 1.0:
+        assert cen.tolist() == ocen.tolist()
+    assert proc.get_mean_centroid(olab.to(torch.uint8).to(dev)).tolist() == ocen.tolist()
+    # the box arithmetic on hand-made masks, one empty
+    m = torch.zeros(4, 40, 56, dtype=torch.uint8)
+    m[0, 5:11, 7:30] = 1
+    m[1, 39, 55] = 1
+    m[3, 0:40, 20:21] = 1
+    assert proc.get_mean_centroid(m.to(dev)).tolist() == oproc.get_mean_centroid(m.long()).tolist()
+    from cineflow import ops
+    assert ops.frame_boxes(m.to(dev)).cpu().tolist() == [[7, 5, 29, 10], [55, 39, 55, 39], [-1, -1, -1, -1], [20, 0, 20, 39]]
+    assert ops.frame_boxes(m.float().to(dev)).cpu().tolist() == ops.frame_boxes(m.to(dev)).cpu().tolist()

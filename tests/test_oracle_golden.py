@@ -285,3 +285,18 @@ def test_dice_and_epe():
     g[:, 0] += 3
     g[:, 1] += 4
     assert abs(OO.mean_epe(f, g) - 5.0) < 1e-12
+
+
+def test_processor_mean_centroid_known_answers():
+    """Processor.get_mean_centroid (processor.py:140-160) worked by hand: bounding-box centres per frame, (H/2, W/2) -- in that order --
+    for an empty frame, the mean truncated by .int()."""
+    import torch
+    from oracle import models as OM
+    p = OM.Processor(32, 64)
+    m = torch.zeros(3, 20, 30, dtype=torch.int64)
+    m[0, 4:9, 10:21] = 2          # x 10..20, y 4..8  -> (15, 6)
+    m[2, 0:2, 0:5] = 1            # x 0..4,  y 0..1  -> (2, 0.5)
+    assert p.get_mean_centroid(m).tolist() == [9, 7]          # frame 1 is empty: (H/2, W/2) = (10, 15); means (9.0, 7.17)
+    m[1, 19, 29] = 3              # a single pixel: (29, 19)
+    assert p.get_mean_centroid(m).tolist() == [15, 8]         # (15+29+2)/3 = 15.33, (6+19+0.5)/3 = 8.5
+    assert OM.masks_to_boxes(m[:1]).tolist() == [[10.0, 4.0, 20.0, 8.0]]

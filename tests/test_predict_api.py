@@ -455,3 +455,45 @@ def test_flow_wrapper_values_vs_oracle(dev, shape, centroid, with_target):
         win = oproc.adjust_cropping_window(centroid)["crop_indices"]
         assert float(np.abs(ofl).max()) > 0
     assert float(np.abs(flow[0]).max()) == 0.0          # ED frame: no flow
+
+
+@pytest.mark.gpu
+def test_flow_wrapper_with_cropping_network_vs_oracle(dev):
+    """No centroid given: every slice is cropped around the mean centroid of the cropping network's masks
+    (SegFlowGaussian.py:3099-3103 -> processor.py:232-237), so padding_need differs between slices; values against the oracle, which
+    gets its centroid from its own restatement of the same chain."""
+    from cineflow import predict as P
+    from cineflow.weights import seeded_state_dict, fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    red = dict(in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=32, bottleneck_heads=4, dim_feedforward=48)
+    plans = P.default_plans(image_size=96, crop_size=64, flow_variant="video", seg_base=8, seg_pool=3, reduced=red)
+    plans["cropping_net"] = {"base_num_features": 8, "num_pool": 3}
+    tr = P.CineTrainer(plans, dev)
+    sd_s = seeded_state_dict(tr.seg_net.state_shapes(), 10)
+    sd_f = seeded_state_dict({k: v for k, v in tr.flow_net.state_shapes().items() if not k.endswith("grid")}, 11)
+    sd_c = seeded_state_dict(tr.crop_net.state_shapes(), 52)
+    tr.load_checkpoint_ram({"seg_state_dict": sd_s, "flow_state_dict": sd_f, "crop_state_dict": sd_c})
+    ofnet = fill_module_(OM.SegFlowGaussian(image_size=64, motion_appearance=False, **red), 11)
+    osnet = fill_module_(OM.GenericUNet2D(1, 8, 4, 3), 10)
+    ocnet = fill_module_(OM.GenericUNet2D(1, 8, 2, 3), 52)
+    oproc = OM.Processor(64, 96, lambda x: {"pred": ocnet(x)})
+    g = torch.Generator().manual_seed(14)
+    T, Z, Y, X = 4, 3, 90, 100
+    unl = (torch.randn(T, 1, Z, Y, X, generator=g) * 30 + 80).numpy().astype(np.float32)
+    unl[:, :, 1, :, :50] *= 0.05          # slice 1: the left half nearly dark -> another mask, another window
+    seg, softmax, flow, reg, _raw, crop = tr.predict_preprocessed_data_return_seg_and_softmax_flow(unl, return_crop=True)
+    assert crop["padding_need"].shape == (4, Z)
+    for z in range(Z):
+        data = OM.pad_nd_image(unl[:, :, z], (96, 96), "constant", {"constant_values": 0}, False)
+        Hh, Ww = data.shape[-2:]
+        y1, x1 = int(Hh / 2 - 48), int(Ww / 2 - 48)
+        with torch.no_grad():
+            ocen = oproc.preprocess_no_registration(torch.from_numpy(np.ascontiguousarray(data[:, :, y1:y1 + 96, x1:x1 + 96])))[0]
+        assert crop["padding_need"][:, z].tolist() == oproc.adjust_cropping_window(ocen)["padding_need"].tolist()
+        oseg, osm, ofl, oreg = OM.predict_2d_tiled_flow(ofnet, osnet, unl[:, :, z], None, oproc, ocen, (96, 96))
+        assert float(np.abs(softmax[:, :, z] - osm).max()) <= 5e-5
+        assert OO.mean_epe(torch.from_numpy(flow[:, :, z]), torch.from_numpy(ofl)) <= 1e-4
+        for k in range(4):
+            d = OO.dice(reg[:, 0, z], oreg[:, 0], k)
+            assert np.isnan(d) or abs(d - 1.0) <= 1e-3
