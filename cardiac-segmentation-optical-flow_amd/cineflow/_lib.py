@@ -51,6 +51,7 @@ SIGNATURES = {
     "cf_group_norm": [P, P, P, P, P, I, I, I, I, F, I, I, P, P],
     "cf_layer_norm_cf": [P, P, P, P, I, I, I, F, P],
     "cf_attention_cf": [P, L, P, L, P, L, P, I, I, I, I, I, P],
+    "cf_attention_cf_masked": [P, L, P, L, P, L, P, I, I, I, I, I, I, P],
     "cf_gru_reset_mul": [P, P, P, I, I, I, P],
     "cf_gru_blend": [P, P, P, P, I, I, I, P],
     "cf_binary": [I, P, P, P, L, L, P],
@@ -93,6 +94,7 @@ SIGNATURES = {
     "cf_spatial_gradient3d": [P, P, L, I, I, I, P],
     "cf_slab_abs_sum": [P, I, I, I, L, P, P],
     "cf_ssim_map": [P, P, I, I, I, DBL, DBL, DBL, P, P],
+    "cf_window_attention": [P, P, P, P, I, I, I, I, I, I, I, P],
     "cf_frame_boxes": [P, I, P, I, I, I, P],
     "cf_sample_points_2d": [P, P, P, I, I, I, I, I, P],
     "cf_profile_enable": [I],

@@ -199,6 +199,7 @@ class Processor:
         nonempty = (ops.frame_boxes(x.view(T, H, W))[:, 0] >= 0)                  # frames with a non-zero pixel
         flat = x.view(T, 1, H * W)
         ops.group_norm(flat, None, None, 1, eps=0.0, out=flat)                    # per-frame z-score (population std), in place
+        x[~nonempty] = 0                                                          # 0 / 0 of an all-zero frame: keep NaN out of the batch
         logits = self.cropping_network(x)["pred"]
         lab = ops.argmax_channels(logits.contiguous())                            # softmax is monotone: argmax of the logits
         lab[~nonempty] = 0

@@ -414,10 +414,23 @@ def _cf_slice(t, name):
 
 
 def attention_cf(q, k, v, heads):
-    """q [B,C,Nq], k/v [B,C,Nk] channel-first; each may be a channel slice of a fused projection buffer."""
+    """q [B,C,Nq], k/v [B,C,Nk] channel-first; each may be a channel slice of a fused projection buffer.  Token counts that are not
+    multiples of 32 (e.g. the 28 x 28 bottleneck of a 224 x 224 image) are zero-padded here and the padded keys masked in the kernel."""
     B, C, Nq = q.shape
     Nk = k.shape[2]
     assert k.shape == (B, C, Nk) and v.shape == (B, C, Nk) and C % heads == 0
+    if Nq % 32 or Nk % 32:
+        Nqp, Nkp = (Nq + 31) // 32 * 32, (Nk + 31) // 32 * 32
+
+        def padded(t, n):
+            p = torch.zeros((B, C, n), dtype=torch.float32, device=t.device)
+            p[:, :, :t.shape[2]] = t
+            return p
+        qp_, kp_, vp_ = padded(q, Nqp), padded(k, Nkp), padded(v, Nkp)
+        out = torch.empty((B, C, Nqp), dtype=torch.float32, device=q.device)
+        check(lib().cf_attention_cf_masked(_f32(qp_), C * Nqp, _f32(kp_), C * Nkp, _f32(vp_), C * Nkp, _f32(out), B, heads, C // heads, Nqp, Nkp, Nk,
+                                           _stream()), "cf_attention_cf_masked")
+        return out[:, :, :Nq].contiguous()
     qp, qbs = _cf_slice(q, "q")
     kp, kbs = _cf_slice(k, "k")
     vp, vbs = _cf_slice(v, "v")
@@ -556,6 +569,16 @@ def argmax_channels(x):
     HW = x.numel() // (B * K)
     out = torch.empty((B,) + tuple(x.shape[2:]), dtype=torch.uint8, device=x.device)
     check(lib().cf_argmax_channels(_f32(x), _u8(out), B, K, HW, _stream()), "cf_argmax_channels")
+    return out
+
+
+def window_attention(qk, v, bias_table, heads, window, shift):
+    """Swin windowed cross-attention core: qk [B,2C,H,W] (q | k of one input), v [B,C,H,W] (of the other), bias_table [(2w-1)^2, heads]
+    -> [B,C,H,W] (nnunet/lib/swin_cross_attention.py:13-112 without the projections)."""
+    B, C, H, W = v.shape
+    assert qk.shape == (B, 2 * C, H, W) and bias_table.shape == ((2 * window - 1) ** 2, heads)
+    out = torch.empty_like(v)
+    check(lib().cf_window_attention(_f32(qk), _f32(v), _f32(bias_table), _f32(out), B, C, H, W, heads, window, shift, _stream()), "cf_window_attention")
     return out
 
 

@@ -17,6 +17,14 @@ def _kind_std(name, shape):
     """Return (kind, std) for one parameter; kinds: 'skip', 'matrix', 'scale', 'bias'."""
     if name.endswith("grid"):  # SpatialTransformer's persistent identity-grid buffer
         return "skip", 0.0
+    if name.endswith(("num_batches_tracked", "relative_position_index", "attn_mask")):   # BatchNorm counter, Swin index / mask buffers
+        return "skip", 0.0
+    if name.endswith("running_var"):        # BatchNorm running variance: positive, away from zero
+        return "var", 0.3
+    if name.endswith("running_mean"):
+        return "bias", 0.2
+    if name.endswith("relative_position_bias_table"):
+        return "matrix", 0.5
     if len(shape) >= 2:
         transposed = (".up.0." in name) or (".tu." in name) or name.startswith("tu.")
         fan_in = shape[0] * int(math.prod(shape[2:])) if transposed else int(math.prod(shape[1:]))
@@ -39,6 +47,8 @@ def seeded_tensor(name, shape, seed=0):
     g = torch.Generator(device="cpu")
     g.manual_seed((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
     t = torch.randn(tuple(shape), generator=g, dtype=torch.float32)
+    if kind == "var":
+        return 0.6 + std * t.abs()
     if kind == "scale":
         return 1.0 + std * t
     return std * t

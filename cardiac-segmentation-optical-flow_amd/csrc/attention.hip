@@ -17,7 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int D>
 __global__ void __launch_bounds__(256) attention_cf_kernel(const float* __restrict__ q, long q_bs, const float* __restrict__ k,
                                                            long k_bs, const float* __restrict__ v, long v_bs,
-                                                           float* __restrict__ out, int heads, int Nq, int Nk, float scale) {
+                                                           float* __restrict__ out, int heads, int Nq, int Nk, float scale, int nk_valid) {
     constexpr int DT = (D + 31) / 32;
     constexpr int VP = 33;  // V row pitch (floats): lanes vary dd at fixed key -> conflict-free
     __shared__ float k_lds[D * 32];
@@ -64,6 +64,11 @@ __global__ void __launch_bounds__(256) attention_cf_kernel(const float* __restri
 #pragma unroll
         for (int s = 0; s < D / 2; ++s)
             sT = __builtin_amdgcn_mfma_f32_32x32x2f32(k_lds[(2 * s + half) * 32 + l31], qf[s], sT, 0, 0, 0);
+        if (kb + 32 > nk_valid) {        // padded keys of a ragged sequence (host pads N to a multiple of 32): out of the softmax
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kb + (r & 3) + 8 * (r >> 2) + 4 * half >= nk_valid) sT[r] = -INFINITY;
+        }
 
         float mx = sT[0];
 #pragma unroll
@@ -129,7 +134,7 @@ __device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
 template <int D>
 __global__ void __launch_bounds__(256, 2) attention_cf_f16s_kernel(const float* __restrict__ q, long q_bs, const float* __restrict__ k,
                                                                   long k_bs, const float* __restrict__ v, long v_bs,
-                                                                  float* __restrict__ out, int heads, int Nq, int Nk, float scale) {
+                                                                  float* __restrict__ out, int heads, int Nq, int Nk, float scale, int nk_valid) {
     constexpr int KS = D / 16;             // k-steps of the score product
     constexpr int DT = (D + 31) / 32;      // 32-row tiles of O^T
     constexpr int KREC = 4 * D + 16;       // bytes per key record  [hi D halves | lo D halves | pad]
@@ -238,6 +243,11 @@ __global__ void __launch_bounds__(256, 2) attention_cf_f16s_kernel(const float* 
                 sT = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sT, 0, 0, 0);
                 sT = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sT, 0, 0, 0);
             }
+            if (kb + 32 > nk_valid) {    // padded keys of a ragged sequence: out of the softmax
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb + (r & 3) + 8 * (r >> 2) + 4 * half >= nk_valid) sT[r] = -INFINITY;
+            }
             float mx = sT[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sT[r]);
@@ -297,9 +307,20 @@ __global__ void __launch_bounds__(256, 2) attention_cf_f16s_kernel(const float* 
 
 using namespace cf;
 
+extern "C" int cf_attention_cf_masked(const float* q, long q_bs, const float* k, long k_bs, const float* v, long v_bs, float* out, int B,
+                                      int heads, int d, int Nq, int Nk, int nk_valid, void* stream);
+
 extern "C" int cf_attention_cf(const float* q, long q_bs, const float* k, long k_bs, const float* v, long v_bs, float* out, int B,
                                int heads, int d, int Nq, int Nk, void* stream) {
+    return cf_attention_cf_masked(q, q_bs, k, k_bs, v, v_bs, out, B, heads, d, Nq, Nk, Nk, stream);
+}
+
+// The same with only the first nk_valid keys taking part in the softmax: a sequence whose length is not a multiple of 32 is padded by
+// the caller (q, k, v zero-filled up to Nq, Nk; the padded query rows of `out` are discarded).
+extern "C" int cf_attention_cf_masked(const float* q, long q_bs, const float* k, long k_bs, const float* v, long v_bs, float* out, int B,
+                                      int heads, int d, int Nq, int Nk, int nk_valid, void* stream) {
     CF_REQUIRE(q && k && v && out, "null pointer");
+    CF_REQUIRE(nk_valid > 0 && nk_valid <= Nk && nk_valid > Nk - 32, "nk_valid must lie in the last 32-key block (Nk=%d nk_valid=%d)", Nk, nk_valid);
     CF_REQUIRE(B > 0 && heads > 0 && Nq > 0 && Nk > 0, "bad shape");
     CF_REQUIRE(Nq % 32 == 0 && Nk % 32 == 0, "token counts must be multiples of 32 (Nq=%d Nk=%d)", Nq, Nk);
     CF_REQUIRE(d == 8 || d == 16 || d == 32 || d == 64, "head dim %d unsupported (8,16,32,64)", d);
@@ -313,18 +334,118 @@ extern "C" int cf_attention_cf(const float* q, long q_bs, const float* k, long k
     if (f32_only < 0) { const char* e = getenv("CF_ATTN_F32"); f32_only = e ? atoi(e) : 0; }
     const bool valign = ((reinterpret_cast<uintptr_t>(v) | (uintptr_t)(v_bs * 4)) & 15) == 0 && (Nk & 7) == 0;
     if (!f32_only && d >= 16 && valign) {
-        if (d == 16) hipLaunchKernelGGL((attention_cf_f16s_kernel<16>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale);
-        else if (d == 32) hipLaunchKernelGGL((attention_cf_f16s_kernel<32>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale);
-        else hipLaunchKernelGGL((attention_cf_f16s_kernel<64>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale);
+        if (d == 16) hipLaunchKernelGGL((attention_cf_f16s_kernel<16>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale, nk_valid);
+        else if (d == 32) hipLaunchKernelGGL((attention_cf_f16s_kernel<32>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale, nk_valid);
+        else hipLaunchKernelGGL((attention_cf_f16s_kernel<64>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale, nk_valid);
         CF_CHECK_LAUNCH();
         return CF_OK;
     }
     switch (d) {
-        case 8: hipLaunchKernelGGL((attention_cf_kernel<8>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale); break;
-        case 16: hipLaunchKernelGGL((attention_cf_kernel<16>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale); break;
-        case 32: hipLaunchKernelGGL((attention_cf_kernel<32>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale); break;
-        default: hipLaunchKernelGGL((attention_cf_kernel<64>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale); break;
+        case 8: hipLaunchKernelGGL((attention_cf_kernel<8>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale, nk_valid); break;
+        case 16: hipLaunchKernelGGL((attention_cf_kernel<16>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale, nk_valid); break;
+        case 32: hipLaunchKernelGGL((attention_cf_kernel<32>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale, nk_valid); break;
+        default: hipLaunchKernelGGL((attention_cf_kernel<64>), grid, dim3(256), 0, s, q, q_bs, k, k_bs, v, v_bs, out, heads, Nq, Nk, scale, nk_valid); break;
     }
+    CF_CHECK_LAUNCH();
+    return CF_OK;
+}
+
+// =====================================================================================================================
+// Windowed cross-attention of the Swin skip filter (nnunet/lib/swin_cross_attention.py:13-112, :292-380): for every window of
+// ws x ws tokens and every head, out = softmax(scale * q k^T + relative-position bias + shift mask) v, with q and k taken from one
+// projected map and v from another.  The cyclic shift, the window partition, window_reverse and the roll back are index arithmetic:
+// token (ty, tx) of window (wy, wx) sits at shifted position (ys, xs) = (wy*ws + ty, wx*ws + tx), i.e. at (ys + shift) mod H in the
+// un-shifted map, and the result is written back to that same place.  Tokens of different border regions of the shifted image do not
+// see each other (-100 on the logits, as the reference's attn_mask).  One workgroup per (sample, window, head): the window's q, k, v
+// (N <= 64 tokens x hd <= 64) sit in LDS, thread (row i, quarter) owns 16 columns of the score row; fp32 throughout -- this network is
+// the cropping / segmentation front end, not the frames/s path.
+namespace cf {
+
+__global__ void __launch_bounds__(256) window_attention_kernel(const float* __restrict__ qk, const float* __restrict__ v, const float* __restrict__ bias_table,
+                                                              float* __restrict__ out, int C, int H, int W, int heads, int ws, int shift, float scale) {
+    extern __shared__ float sm[];
+    const int hd = C / heads, N = ws * ws;
+    float* sq = sm;                    // [N][hd + 1]
+    float* sk = sq + N * (hd + 1);
+    float* sv = sk + N * (hd + 1);
+    float* sp = sv + N * (hd + 1);     // [N][N + 1]
+    const int nwx = W / ws, nwy = H / ws;
+    int bid = blockIdx.x;
+    const int head = bid % heads;
+    bid /= heads;
+    const int wx = bid % nwx;
+    bid /= nwx;
+    const int wy = bid % nwy;
+    const int b = bid / nwy;
+    const long HW = (long)H * W;
+    const float* qb = qk + ((long)b * 2 * C + head * hd) * HW;
+    const float* kb = qb + (long)C * HW;
+    const float* vb = v + ((long)b * C + head * hd) * HW;
+    for (int e = threadIdx.x; e < N * hd; e += blockDim.x) {
+        const int n = e % N, d = e / N;                       // token fastest: neighbouring lanes read neighbouring pixels
+        const int ys = wy * ws + n / ws, xs = wx * ws + n % ws;
+        const long pix = (long)((ys + shift) % H) * W + (xs + shift) % W;
+        sq[n * (hd + 1) + d] = qb[d * HW + pix] * scale;
+        sk[n * (hd + 1) + d] = kb[d * HW + pix];
+        sv[n * (hd + 1) + d] = vb[d * HW + pix];
+    }
+    __syncthreads();
+    auto region = [&](int p, int S) { return p < S - ws ? 0 : (p < S - shift ? 1 : 2); };
+    // scores: thread -> (row i, column j) pairs
+    for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
+        const int i = e / N, j = e % N;
+        float acc = 0.f;
+        for (int d = 0; d < hd; ++d) acc = fmaf(sq[i * (hd + 1) + d], sk[j * (hd + 1) + d], acc);
+        const int tyi = i / ws, txi = i % ws, tyj = j / ws, txj = j % ws;
+        acc += bias_table[((tyi - tyj + ws - 1) * (2 * ws - 1) + (txi - txj + ws - 1)) * heads + head];
+        if (shift > 0) {
+            const int ri = 3 * region(wy * ws + tyi, H) + region(wx * ws + txi, W), rj = 3 * region(wy * ws + tyj, H) + region(wx * ws + txj, W);
+            if (ri != rj) acc += -100.0f;
+        }
+        sp[i * (N + 1) + j] = acc;
+    }
+    __syncthreads();
+    // softmax per row (one thread per row: N <= 64 rows, short rows)
+    if ((int)threadIdx.x < N) {
+        float* row = sp + threadIdx.x * (N + 1);
+        float mx = -INFINITY;
+        for (int j = 0; j < N; ++j) mx = fmaxf(mx, row[j]);
+        float sum = 0.f;
+        for (int j = 0; j < N; ++j) { row[j] = expf(row[j] - mx); sum += row[j]; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < N; ++j) row[j] *= inv;
+    }
+    __syncthreads();
+    float* ob = out + ((long)b * C + head * hd) * HW;
+    for (int e = threadIdx.x; e < N * hd; e += blockDim.x) {
+        const int n = e % N, d = e / N;
+        float acc = 0.f;
+        for (int j = 0; j < N; ++j) acc = fmaf(sp[n * (N + 1) + j], sv[j * (hd + 1) + d], acc);
+        const int ys = wy * ws + n / ws, xs = wx * ws + n % ws;
+        ob[d * HW + (long)((ys + shift) % H) * W + (xs + shift) % W] = acc;
+    }
+}
+
+}  // namespace cf
+
+extern "C" int cf_window_attention(const float* qk, const float* v, const float* bias_table, float* out, int B, int C, int H, int W, int heads,
+                                   int window, int shift, void* stream) {
+    CF_REQUIRE(qk && v && bias_table && out, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && heads > 0 && C % heads == 0, "bad shape");
+    CF_REQUIRE(window > 0 && window <= 8 && H % window == 0 && W % window == 0, "window %d must divide the map %dx%d (and be <= 8)", window, H, W);
+    CF_REQUIRE(shift >= 0 && shift < window, "shift must be in [0, window)");
+    const int hd = C / heads, N = window * window;
+    CF_REQUIRE(hd <= 64, "head dim %d > 64", hd);
+    const size_t lds = sizeof(float) * ((size_t)3 * N * (hd + 1) + (size_t)N * (N + 1));
+    const long nblk = (long)B * (H / window) * (W / window) * heads;
+    CF_REQUIRE(nblk < (1L << 31), "too many windows");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cf::window_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cf::window_attention_kernel, dim3((unsigned)nblk), dim3(256), lds, cf::as_stream(stream), qk, v, bias_table, out, C, H, W, heads, window,
+                       shift, (float)(1.0 / sqrt((double)hd)));
     CF_CHECK_LAUNCH();
     return CF_OK;
 }

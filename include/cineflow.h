@@ -121,7 +121,8 @@ int cf_conv2d(const float* x1, int C1, const float* x2, int C2, const float* wt,
  * Sizes: the kernel addresses its inputs with 32-bit offsets; ONE SAMPLE of x1 / x2 must stay below 2 GiB, a batch of any
  * size is cut into sub-batches inside the library (same kernel, same numbers).
  * Activation range: |x| < 65504 (fp16's range for the hi half).  Larger magnitudes, Inf and NaN are not clamped: they come
- * out as NaN, as loudly as in an fp32 convolution fed with NaN.  Below 2^-14 |x| the lo half goes subnormal (absolute error
+ * out as NaN, as loudly as in an fp32 convolution fed with NaN -- and, when Cin is not a multiple of the chunk size, the channel tail of
+ * sample b is read from the first channels of sample b + 1 (against zero weights), so a NaN there also poisons sample b.  Below 2^-14 |x| the lo half goes subnormal (absolute error
  * 2^-25), which is under the fp32 rounding of the sum for the normalised activations this path is built for.
  * gn_ws (nullable, 2*B*gn_groups doubles): on return it holds the GroupNorm / InstanceNorm statistics (sum, sum of squares
  * per (sample, group)) of the OUTPUT, accumulated in the conv epilogue (or by a statistics pass when a workgroup spans
@@ -181,6 +182,10 @@ int cf_layer_norm_cf(const float* x, const float* gamma, const float* beta, floa
  * of a fused projection buffer); out [B,heads*d,Nq] contiguous.  d in {8,16,32,64}; Nq,Nk multiples of 32. */
 int cf_attention_cf(const float* q, long q_bs, const float* k, long k_bs, const float* v, long v_bs, float* out, int B,
                     int heads, int d, int Nq, int Nk, void* stream);
+/* cf_attention_cf for sequences whose length is not a multiple of 32: the caller zero-pads q / k / v to Nq, Nk (multiples of 32); only
+ * the first nk_valid keys take part in the softmax (nk_valid in the last 32-key block); padded query rows of `out` are garbage. */
+int cf_attention_cf_masked(const float* q, long q_bs, const float* k, long k_bs, const float* v, long v_bs, float* out, int B,
+                           int heads, int d, int Nq, int Nk, int nk_valid, void* stream);
 
 /* ---------------------------------------------------------------- ConvGRU gating (convGRU.py:60-68)
  * gates [B,2C,HW] = sigmoid(conv_gates(...)) with channels [0,C) = reset, [C,2C) = update. */
@@ -306,6 +311,13 @@ int cf_slab_abs_sum(const float* x, int C, int A, int S, long B, double* sums, v
  * S (fp64 [H][W]) = SSIM of every pixel from the five local means with scipy's 'reflect' boundary; C1 = (K1 R)^2, C2 = (K2 R)^2,
  * cov_norm = NP / (NP - 1).  The mean over the interior (cf_region_stats on the cropped map) is the score. */
 int cf_ssim_map(const double* im1, const double* im2, int H, int W, int win, double C1, double C2, double cov_norm, double* S, void* stream);
+
+/* SwinCrossAttention (nnunet/lib/swin_cross_attention.py:13-112) after the projections: qk [B][2C][H][W] = the q and k maps of the
+ * "rescaler" input, v [B][C][H][W] the value map of the "rescaled" input, bias_table [(2w-1)^2][heads] the learned relative position
+ * bias; out [B][C][H][W] = softmax(q k^T / sqrt(C/heads) + bias + shift mask) v per window of w x w tokens (w <= 8 dividing H and W),
+ * windows taken on the map cyclically shifted by `shift` and written back un-shifted. */
+int cf_window_attention(const float* qk, const float* v, const float* bias_table, float* out, int B, int C, int H, int W, int heads,
+                        int window, int shift, void* stream);
 
 /* Processor.get_mean_centroid's masks_to_boxes (training/network_training/processor.py:140-160): per frame n of x [N][H][W]
  * (uint8, or float32 when is_float) boxes[n] = {x1, y1, x2, y2} of the non-zero pixels, or {-1,-1,-1,-1} for an all-zero frame. */
