@@ -311,8 +311,8 @@ def bench_raft(args, dev, h, world, rank, steps, warmup):
                                "correlation pyramid (fmaps [B,256,32,32], 4 levels), 12 x (lookup r=4 -> motion encoder -> SepConvGRU -> flow / mask "
                                "heads -> convex upsampling), memory-encoder refresh", "pairs_per_step_per_gpu": B, "image": "256x256"},
         "roofline": roofline,
-        "roofline_allpairs": hbm_roofline("all-pairs volume (conv_igemm_f32 with per-sample weights) + 3 pyramid poolings; 7.67 MB / pair", allp),
-        "roofline_lookup": hbm_roofline("corr_lookup_kernel (324 channels written once per iteration)", look),
+        "roofline_allpairs": hbm_roofline("allpairs_pyramid_kernel (f16-split MFMA product, the 4 pyramid levels from one set of accumulators); 7.67 MB / pair", allp),
+        "roofline_lookup": hbm_roofline("corr_lookup_tiled_kernel (324 channels written once per iteration; gathers are cache traffic)", look),
         "roofline_upsample": hbm_roofline("convex_upsample_kernel (576-channel mask read once per iteration)", up),
     }
 

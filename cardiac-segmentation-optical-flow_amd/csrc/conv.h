@@ -37,6 +37,9 @@ int launch_conv(const ConvParams& p, hipStream_t s);
 bool conv_f16s_supported(const ConvParams& p);
 int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s);
 
+// RAFT all-pairs volume + pyramid in one kernel (allpairs.hip); returns 1 when the shape is not one it is built for
+int allpairs_pyramid_fused(const float* f1, const float* f2, float* pyr, int B, int C, int H, int W, int levels, hipStream_t stream);
+
 // GroupNorm statistics pass (norm.hip): ws[2*(b*groups+g)] = sum, +1 = sum of squares, fp64
 int launch_gn_stats(const float* x, double* ws, int B, int C, int HW, int groups, hipStream_t s);
 

@@ -398,6 +398,56 @@ __global__ void __launch_bounds__(256) corr_lookup_kernel(const float* __restric
     }
 }
 
+// The same lookup for radius 4 / N % 64 == 0, laid out for the memory system.  The flat kernel above gives every output its own
+// thread: neighbouring lanes are neighbouring PIXELS, i.e. different correlation planes (4 KiB apart at level 0), so each of its four
+// gathers touches 64 cache lines and each store scatters 4-byte pieces 4 KiB apart (measured 427 GB/s of algorithmic traffic, 5 % of
+// the HBM peak).  Here a workgroup owns 64 consecutive pixels of one sample, wave l owns pyramid level l, and inside a wave the lanes
+// are (pixel 0..6) x (x-offset i 0..8): the taps of one gather lie side by side in 7 planes, and the 324 x 64 outputs leave through
+// LDS as whole 256-byte rows.  Arithmetic per output is unchanged (same rounding path as the flat kernel).
+constexpr int LK_D = 9, LK_G = 7;      // offsets per axis, pixels per wave pass
+template <int LK_PIX>                  // pixels per workgroup: 64 (256-byte rows, 84 KB of LDS) or 32 (128-byte rows, three workgroups per CU)
+__global__ void __launch_bounds__(256) corr_lookup_tiled_kernel(const float* __restrict__ pyr, const float* __restrict__ coords,
+                                                               float* __restrict__ out, int B, int H, int W, int levels) {
+    extern __shared__ float stage[];                 // [levels * 81][LK_PIX + 1]
+    const int N = H * W;
+    const int tiles = N / LK_PIX;
+    const int b = blockIdx.x / tiles, n0 = (blockIdx.x % tiles) * LK_PIX;
+    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;       // wave = pyramid level (levels <= 4)
+    const int pl = lane / LK_D, i = lane - pl * LK_D;              // pixel inside the pass, x-offset index
+    if (l < levels) {
+        long off = 0;
+        for (int q = 0; q < l; ++q) off += (long)B * N * (H >> q) * (W >> q);
+        const int Hl = H >> l, Wl = W >> l;
+        const float inv = 1.0f / (float)(1 << l);
+        for (int p0 = 0; p0 < LK_PIX; p0 += LK_G) {
+            const int p = p0 + pl;
+            if (lane < LK_G * LK_D && p < LK_PIX) {
+                const int n = n0 + p;
+                const float* plane = pyr + off + ((long)b * N + n) * Hl * Wl;
+                const float cx = __fadd_rn(__fmul_rn(coords[(long)b * 2 * N + n], inv), (float)(i - 4));
+                const float gx = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, cx), (float)(Wl - 1)), 1.0f);
+                const float x = __fmul_rn(__fdiv_rn(__fadd_rn(gx, 1.0f), 2.0f), (float)(Wl - 1));
+                const float ybase = __fmul_rn(coords[(long)b * 2 * N + N + n], inv);
+#pragma unroll
+                for (int j = 0; j < LK_D; ++j) {
+                    const float cy = __fadd_rn(ybase, (float)(j - 4));
+                    const float gy = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, cy), (float)(Hl - 1)), 1.0f);
+                    const float y = __fmul_rn(__fdiv_rn(__fadd_rn(gy, 1.0f), 2.0f), (float)(Hl - 1));
+                    Taps t = make_taps(y, x, Hl, Wl);
+                    stage[(l * 81 + i * LK_D + j) * (LK_PIX + 1) + p] = sample_taps(plane, t, Wl);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int CH = levels * 81;
+    float* ob = out + (long)b * CH * N + n0;
+    for (int e = threadIdx.x; e < CH * LK_PIX; e += 256) {
+        const int ch = e / LK_PIX, p = e % LK_PIX;
+        ob[(long)ch * N + p] = stage[ch * (LK_PIX + 1) + p];
+    }
+}
+
 // convex upsampling: thread = (b, i, j, y, x) with x fastest -> the 9 mask reads are coalesced
 __global__ void __launch_bounds__(256) convex_upsample_kernel(const float* __restrict__ flow, const float* __restrict__ mask,
                                                              float* __restrict__ out, int B, int C, int h, int w) {
@@ -472,6 +522,15 @@ extern "C" int cf_corr_pyramid(const float* f1, const float* f2, float* pyr, int
     CF_REQUIRE((H >> (levels - 1)) >= 2 && (W >> (levels - 1)) >= 2, "coarsest level must be at least 2x2");
     hipStream_t s = as_stream(stream);
     const int N = H * W;
+    {   // the fused f16-split kernel (level 0 and the pooled levels from one set of accumulators) when the shape allows; CF_ALLPAIRS_FUSED=0
+        // keeps the fp32-MFMA GEMM + three pooling launches (A/B knob, and the path of other map widths)
+        static int fused = -1;
+        if (fused < 0) { const char* e = getenv("CF_ALLPAIRS_FUSED"); fused = e ? atoi(e) : 1; }
+        if (fused) {
+            const int rc = allpairs_pyramid_fused(f1, f2, pyr, B, C, H, W, levels, s);
+            if (rc != 1) return rc;
+        }
+    }
     // level 0: out[b, n1, n2] = sum_c f1[b,c,n1] * f2[b,c,n2] / sqrt(C): a 1x1 "conv" of f2 with per-sample weights Wt[k=c][m=n1] = f1[b]
     ConvParams p;
     p.x1 = f2; p.x2 = nullptr; p.wt = f1; p.bias = nullptr; p.res = nullptr; p.out = pyr; p.w_bstride = (long)C * N;
@@ -501,6 +560,29 @@ extern "C" int cf_corr_lookup(const float* pyr, const float* coords, float* out,
     CF_REQUIRE(B > 0 && H > 0 && W > 0 && levels >= 1 && levels <= 6 && radius >= 0 && radius <= 8, "bad shape");
     CF_REQUIRE((H >> (levels - 1)) >= 2 && (W >> (levels - 1)) >= 2, "coarsest level must be at least 2x2");
     long total = (long)B * levels * (2 * radius + 1) * (2 * radius + 1) * H * W;
+    static int tiled = -1;
+    if (tiled < 0) { const char* e = getenv("CF_LOOKUP_TILED"); tiled = e ? atoi(e) : 1; }      // 0: the flat kernel everywhere (A/B knob)
+    if (tiled && radius == 4 && levels <= 4 && (H * W) % 64 == 0) {
+        const int pix = tiled == 1 ? 16 : (tiled == 2 ? 32 : 64);       // measured at B = 64: 64 px 208 us (one workgroup per CU), 32 px 94 us, 16 px 76 us
+        const size_t lds = sizeof(float) * (size_t)levels * 81 * (pix + 1);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_lookup_tiled_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_lookup_tiled_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(corr_lookup_tiled_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr_set = true;
+        }
+        hipStream_t st = as_stream(stream);
+        const dim3 grid((unsigned)((long)B * (H * W / pix)));
+        auto kern = pix == 64 ? corr_lookup_tiled_kernel<64> : (pix == 32 ? corr_lookup_tiled_kernel<32> : corr_lookup_tiled_kernel<16>);
+        hipEvent_t e0, e1;
+        if (profile_on() && profile_events(PK_CORR_LOOKUP, 4.0 * total + 8.0 * B * H * W, &e0, &e1))
+            hipExtLaunchKernelGGL(kern, grid, dim3(256), lds, st, e0, e1, 0, pyr, coords, out, B, H, W, levels);
+        else
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, pyr, coords, out, B, H, W, levels);
+        CF_CHECK_LAUNCH();
+        return CF_OK;
+    }
     // algorithmic bytes: the written channels + coords once; the gathers (<= 4 per output) are cache traffic
     launch_profiled(PK_CORR_LOOKUP, 4.0 * total + 8.0 * B * H * W, corr_lookup_kernel, dim3(flat_grid(total, 256)), dim3(256), as_stream(stream), pyr,
                     coords, out, B, H, W, levels, radius);

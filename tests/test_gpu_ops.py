@@ -200,6 +200,30 @@ def test_allpairs_pyramid_lookup(dev):
     check(ops.coords_grid(B, H, W, dev), OO.coords_grid(B, H, W), 0)
 
 
+def test_allpairs_pyramid_fused_full_size(dev):
+    """RAFT at 1/8 of 256 x 256: 256-channel 32 x 32 maps, 4 levels -- the fused f16-split kernel (level 0 and the three pooled levels from
+    one set of accumulators), then the tiled lookup, against the oracle; and the fused pooled levels against pooling the stored level 0
+    (bit-compatible by construction)."""
+    import torch.nn.functional as F_
+    from cineflow import ops
+    from oracle import ops as OO
+    B, C, H, W = 3, 256, 32, 32
+    f1, f2 = randn(B, C, H, W, seed=27), randn(B, C, H, W, seed=28)
+    pyr = ops.corr_pyramid(f1.to(dev), f2.to(dev), 4)
+    ref = OO.corr_pyramid(OO.corr_allpairs(f1, f2), 4)
+    off, lv = 0, []
+    for l, r in enumerate(ref):
+        n = r.numel()
+        lv.append(pyr[off:off + n].view(r.shape).cpu())
+        check(lv[-1], r, 3e-5, "level %d" % l)
+        off += n
+    for l in range(1, 4):
+        assert torch.equal(lv[l], F_.avg_pool2d(lv[l - 1], 2, stride=2)), "level %d is not the pool of the stored level %d" % (l, l - 1)
+    coords = OO.coords_grid(B, H, W) + 3.0 * randn(B, 2, H, W, seed=29)
+    out = ops.corr_lookup(pyr, coords.to(dev), 4, 4)
+    check(out, OO.corr_lookup(ref, coords, 4), 3e-5, "lookup")
+
+
 def test_convex_upsample(dev):
     from cineflow import ops
     from oracle import ops as OO
