@@ -451,3 +451,4 @@ def test_processor_centroid_vs_oracle(dev):
     from cineflow import ops
     assert ops.frame_boxes(m.to(dev)).cpu().tolist() == [[7, 5, 29, 10], [55, 39, 55, 39], [-1, -1, -1, -1], [20, 0, 20, 39]]
     assert ops.frame_boxes(m.float().to(dev)).cpu().tolist() == ops.frame_boxes(m.to(dev)).cpu().tolist()
+

@@ -70,17 +70,17 @@ def main():
     ap.add_argument("--top", type=int, default=60)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
-    fnet, snet = bench.build_nets(dev, "video", 1234, 1, 0)
+    fnet, snet = bench.load_nets(bench.make_nets("video"), dev, 1234, 1, 0)
     frames = bench.synthetic_cine(a.slices, a.frames, 256, 1234).to(dev)
     lab = torch.zeros(a.slices, 256, 256, dtype=torch.uint8, device=dev)
     lab[:, 100:156, 100:156] = 1
-    bench.run_step(fnet, snet, frames, lab, 120)
+    bench.run_step(fnet, snet, frames, lab)
     torch.cuda.synchronize()
     for n in ("conv2d_f16s", "conv2d_f16s_prenorm", "conv2d_small_cin", "group_norm_coef", "conv_transpose2d_k2s2_f16s", "group_norm_apply", "group_norm", "layer_norm_cf", "attention_cf", "corr_volume",
               "warp_bilinear", "binary", "copy_channels", "gru_reset_mul", "gru_blend", "tta_accumulate", "warp_labels", "memory_input"):
         wrap(n)
     # modules bound `ops.X` at call time through the module attribute, so the wrappers are picked up
-    bench.run_step(fnet, snet, frames, lab, 120)
+    bench.run_step(fnet, snet, frames, lab)
     torch.cuda.synchronize()
     tot = sum(s[1] for s in STATS.values())
     print("total wrapped time %.1f ms" % tot)

@@ -1,0 +1,13 @@
+#!/bin/bash
+# rocprofv3 kernel-trace statistics of one bench step (run on the GPU box through gpurun).  Usage: tools/rocprof_bench.sh <tag> [bench args...]
+# Writes gpurun_out/<tag>_kernel_stats.csv (copy the ones to be judged into profiles/).
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
+rm -rf "$out"
+rocprofv3 --kernel-trace --stats -d "$out" -o "$tag" -- python3 "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --steps 1 --warmup 1 "$@" > "$GRAFT_REPO_ROOT/gpurun_out/${tag}_bench.log" 2>&1
+rc=$?
+f=$(find "$out" -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" "$GRAFT_REPO_ROOT/gpurun_out/${tag}_kernel_stats.csv"
+tail -1 "$GRAFT_REPO_ROOT/gpurun_out/${tag}_bench.log" | cut -c1-300
+exit $rc
