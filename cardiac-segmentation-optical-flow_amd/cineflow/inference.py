@@ -5,6 +5,8 @@ nnunet/network_architecture/SegFlowGaussian.py, with the per-tile host<->device 
 tiles, mirrored copies, Gaussian weighting, accumulation, argmax and the label warp all stay in HBM, and every tile
 of every slice goes through the network as ONE batch.  `file:line` citations are relative to /root/reference.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -288,6 +290,19 @@ def chunk_orders(T):
     return [0] + c1, [0] + c2[::-1]
 
 
+# CF_TWO_STREAMS=1: segmentation U-Net and flow recurrence on two HIP streams.  Measured +2.6 % frames/s (676.7 vs 659.2 on one box); OFF by
+# default because overlapping kernels make the per-kernel event durations of bench.py's roofline (and rocprof's) meaningless.
+TWO_STREAMS = os.environ.get("CF_TWO_STREAMS", "0") == "1"
+_side = {}
+
+
+def _side_stream(dev):
+    key = str(dev)
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=dev)
+    return _side[key]
+
+
 def predict_cine_slices(flow_net, seg_net, frames, ed_labels=None, do_mirroring=True, mirror_axes=(0, 1)):
     """The joint hot path of BASELINE.json config 4 for a batch of slices that are already cropped to the network's
     patch (SegFlowGaussian._internal_maybe_mirror_and_pred_2D :3120-3230 + _internal_predict_2D_2Dconv_tiled_flow
@@ -300,9 +315,19 @@ def predict_cine_slices(flow_net, seg_net, frames, ed_labels=None, do_mirroring=
     """
     T, B, _, H, W = frames.shape
     dev = frames.device
-    # segmentation: every frame of every slice is independent -> one batch, flip-TTA on the softmax (:3165-3226)
-    probs = mirror_and_predict_2d(seg_net, frames.reshape(T * B, 1, H, W), mirror_axes, do_mirroring)
-    seg = ops.argmax_channels(probs).view(T, B, H, W)
+    # segmentation: every frame of every slice is independent -> one batch, flip-TTA on the softmax (:3165-3226).  It does not depend on the
+    # flow recurrence, so it CAN be issued on a second HIP stream: the recurrence's small launches (attention, gates, 32x32 maps) leave CUs
+    # idle that the U-Net's large launches fill (opt-in, see TWO_STREAMS)
+    side = None
+    if TWO_STREAMS:
+        side = _side_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            probs = mirror_and_predict_2d(seg_net, frames.reshape(T * B, 1, H, W), mirror_axes, do_mirroring)
+            seg = ops.argmax_channels(probs).view(T, B, H, W)
+    else:
+        probs = mirror_and_predict_2d(seg_net, frames.reshape(T * B, 1, H, W), mirror_axes, do_mirroring)
+        seg = ops.argmax_channels(probs).view(T, B, H, W)
     # flow: two half sequences that both start at ED, the second one backwards in time (:3120-3127); flow is not
     # TTA-averaged (:3162).  Both chunks run as one batch of 2B sequences when they have equal length.
     flow = torch.zeros((T, B, 2, H, W), dtype=torch.float32, device=dev)
@@ -320,6 +345,10 @@ def predict_cine_slices(flow_net, seg_net, frames, ed_labels=None, do_mirroring=
                 bf = flow_net(frames[order].contiguous())["backward_flow"]
                 for j, t in enumerate(order[1:]):
                     flow[t] = bf[j]
+    if side is not None:
+        torch.cuda.current_stream(dev).wait_stream(side)
+        probs.record_stream(torch.cuda.current_stream(dev))
+        seg.record_stream(torch.cuda.current_stream(dev))
     if ed_labels is None:
         ed_labels = seg[0].contiguous()
     registered = ops.warp_labels(flow, ed_labels, flow_net.num_classes if hasattr(flow_net, "num_classes") else 4)
