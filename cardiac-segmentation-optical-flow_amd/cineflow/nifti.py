@@ -91,13 +91,13 @@ def read_nifti(path):
         b, c, d = struct.unpack_from("<3f", raw, 256)
         off = np.array(struct.unpack_from("<3f", raw, 268), dtype=np.float64)
         a2 = 1.0 - (b * b + c * c + d * d)
-        a = np.sqrt(a2) if a2 > 1e-7 else 0.0
+        qa = np.sqrt(a2) if a2 > 1e-7 else 0.0
         if a2 <= 1e-7:
             nrm = 1.0 / np.sqrt(b * b + c * c + d * d)
             b, c, d = b * nrm, c * nrm, d * nrm
-        R = np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
-                      [2 * (b * c + a * d), a * a + c * c - b * b - d * d, 2 * (c * d - a * b)],
-                      [2 * (b * d - a * c), 2 * (c * d + a * b), a * a + d * d - b * b - c * c]], dtype=np.float64)
+        R = np.array([[qa * qa + b * b - c * c - d * d, 2 * (b * c - qa * d), 2 * (b * d + qa * c)],
+                      [2 * (b * c + qa * d), qa * qa + c * c - b * b - d * d, 2 * (c * d - qa * b)],
+                      [2 * (b * d - qa * c), 2 * (c * d + qa * b), qa * qa + d * d - b * b - c * c]], dtype=np.float64)
         if pixdim[0] < 0:
             R[:, 2] = -R[:, 2]
         D = lps2ras @ R

@@ -42,7 +42,9 @@ __global__ void __launch_bounds__(512, 2) allpairs_pyramid_kernel(const float* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int mblocks = N / AP_M, rgroups = H / AP_ROWS;
-    int bid = blockIdx.x;
+    // XCD-banded: consecutive logical ids (the workgroups that share an f2 tile, then the two row groups of a sample) run on ONE XCD and
+    // meet in its L2 -- dispatched round-robin they re-fetched every tile once per XCD (PMC: reads 2.25x algorithmic before this)
+    int bid = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
     const int mb = bid % mblocks;
     bid /= mblocks;
     const int rg = bid % rgroups;
@@ -168,7 +170,7 @@ int allpairs_pyramid_fused(const float* f1, const float* f2, float* pyr, int B, 
     if (!(W == 32 && H % AP_ROWS == 0 && C % AP_CK == 0 && levels == 4 && H >= 16)) return 1;
     const int N = H * W;
     const long nblk = (long)B * (N / AP_M) * (H / AP_ROWS);
-    if (nblk >= (1L << 31)) return 1;
+    if (nblk >= (1L << 31) || (nblk & 7)) return 1;
     // algorithmic bytes: f1 + f2 read once, the four levels written once
     const double bytes = 4.0 * B * (2.0 * C * N + (double)N * N * (1.0 + 0.25 + 0.0625 + 0.015625));
     launch_profiled(PK_ALLPAIRS, bytes, allpairs_pyramid_kernel, dim3((unsigned)nblk), dim3(512), stream, f1, f2, pyr, B, C, H,

@@ -497,3 +497,36 @@ def test_flow_wrapper_with_cropping_network_vs_oracle(dev):
         for k in range(4):
             d = OO.dice(reg[:, 0, z], oreg[:, 0], k)
             assert np.isnan(d) or abs(d - 1.0) <= 1e-3
+
+
+def test_nifti_qform_only_and_4d(tmp_path):
+    """A header with sform_code 0 and a valid qform (scanner / ITK-written files): direction, origin and spacing come from the quaternion,
+    as ITK does; a 4-D file is refused instead of silently truncated."""
+    import struct
+    from cineflow.nifti import read_nifti, write_nifti
+    p = str(tmp_path / "q.nii")
+    write_nifti(p, np.arange(24, dtype=np.int16).reshape(2, 3, 4), (1.0, 1.0, 1.0))
+    raw = bytearray(open(p, "rb").read())
+    th = 0.4                                                   # rotation about z by 0.4 rad in RAS: quaternion (cos, 0, 0, sin) of th / 2
+    struct.pack_into("<h", raw, 252, 1)                        # qform_code
+    struct.pack_into("<h", raw, 254, 0)                        # sform_code off
+    struct.pack_into("<8f", raw, 76, 1.0, 1.5, 2.5, 7.0, 1.0, 1.0, 1.0, 1.0)      # qfac +1, pixdim
+    struct.pack_into("<3f", raw, 256, 0.0, 0.0, float(np.sin(th / 2)))             # quatern b, c, d
+    struct.pack_into("<3f", raw, 268, -10.0, 20.0, 30.0)                          # qoffset (RAS)
+    open(p, "wb").write(bytes(raw))
+    arr, props = read_nifti(p)
+    assert arr.shape == (2, 3, 4) and np.allclose(props["itk_spacing"], (1.5, 2.5, 7.0))
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    lps = np.diag([-1.0, -1.0, 1.0])
+    assert np.allclose(np.array(props["itk_direction"]).reshape(3, 3), lps @ R, atol=1e-6)
+    assert np.allclose(props["itk_origin"], (10.0, -20.0, 30.0))
+    # qfac = -1 flips the third axis
+    struct.pack_into("<f", raw, 76, -1.0)
+    open(p, "wb").write(bytes(raw))
+    _, props = read_nifti(p)
+    assert np.allclose(np.array(props["itk_direction"]).reshape(3, 3)[:, 2], (lps @ R)[:, 2] * -1, atol=1e-6)
+    # 4-D
+    struct.pack_into("<8h", raw, 40, 4, 4, 3, 2, 5, 1, 1, 1)
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(ValueError):
+        read_nifti(p)

@@ -42,4 +42,24 @@ elif kind == "prenorm":      # python tools/one_kernel.py prenorm C H B gelu|lre
     coef = ops.group_norm_coef(ws.clone(), None, None, groups, B, C, H * H)
     for _ in range(5):
         ops.conv2d_f16s_prenorm(x, coef, -1.0 if act == "gelu" else 0.01, wpk, wsc, None, C, stats_groups=groups)
+elif kind == "allpairs":     # python tools/one_kernel.py allpairs B   (fmaps [B,256,32,32], 4 levels)
+    B = int(sys.argv[2])
+    f1, f2 = torch.randn(B, 256, 32, 32, generator=g).to(dev), torch.randn(B, 256, 32, 32, generator=g).to(dev)
+    for _ in range(5):
+        ops.corr_pyramid(f1, f2, 4)
+elif kind == "lookup":       # python tools/one_kernel.py lookup B
+    B = int(sys.argv[2])
+    f1, f2 = torch.randn(B, 256, 32, 32, generator=g).to(dev), torch.randn(B, 256, 32, 32, generator=g).to(dev)
+    pyr = ops.corr_pyramid(f1, f2, 4)
+    coords = ops.coords_grid(B, 32, 32, dev) + 3 * torch.randn(B, 2, 32, 32, generator=g).to(dev)
+    for _ in range(5):
+        ops.corr_lookup(pyr, coords, 4, 4)
+elif kind == "sep":          # python tools/one_kernel.py sep 1x5|5x1 B   (SepConvGRU gates 128+256 -> 256 at 32x32)
+    kh, kw = (1, 5) if sys.argv[2] == "1x5" else (5, 1)
+    B = int(sys.argv[3])
+    x1, x2 = torch.randn(B, 128, 32, 32, generator=g).to(dev), torch.randn(B, 256, 32, 32, generator=g).to(dev)
+    w = (torch.randn(256, 384, kh, kw, generator=g) / math.sqrt(384 * 5)).to(dev)
+    wpk, wsc = ops.pack_conv_weight_f16s(w)
+    for _ in range(5):
+        ops.conv2d_f16s(x1, wpk, wsc, None, 256, kh, kw, 1, (kh // 2, kw // 2), x2=x2)
 torch.cuda.synchronize()
