@@ -383,11 +383,13 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
 #pragma unroll
             for (int grp = 0; grp < NGRP; ++grp) {
                 const int q = c * NGRP + grp;
-                if (q + 1 < nq && g.ablate != 3) issue_w(q + 1);
-                if (grp == 0 && more) {           // (younger than the DMAs: the counted wait at the end of this group leaves them in flight)
-                    if (VEC) issue_loads_v(c + 1, stgv);
-                    else issue_loads(c + 1, stg0);
+                if (q + 1 < nq) issue_w(q + 1);
+                if (grp == 0) {                   // unconditional (the last chunk re-reads itself), younger than the DMAs: the counted wait at the
+                    const int cn = more ? c + 1 : c;      // end of this group leaves them in flight
+                    if (VEC) issue_loads_v(cn, stgv);
+                    else issue_loads(cn, stg0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 const unsigned char* ws = wa + (q & 1) * WSLOT;
 #pragma unroll
                 for (int sg = 0; sg < G; ++sg) {
@@ -413,15 +415,9 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
                 }
                 // group q + 1's fragments must have landed before anyone reads them: vmcnt retires in order, so at the end of group 0 the
                 // patch loads issued after the DMAs (VEC: 4 per task) may stay in flight
-                if (g.ablate != 5) {
-                    if (VEC && grp == 0 && NGRP > 1) {
-                        if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VEC * 4) : "memory");
-                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    } else {
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                }
-                if (g.ablate != 4 || grp == NGRP - 1) __syncthreads();
+                if (VEC && grp == 0 && NGRP > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VEC * 4) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
             }
         }
     } else {
@@ -433,8 +429,12 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     constexpr int D = R - 1;
     f16x8 aH[R] = {}, aL[R] = {};
     auto load_a = [&](int chunk, int step, int slot) {
+#ifdef CF_F16S_ABLATION_BUILD          // timing experiments of profiles/r02_conv_weight_path.md: the run-time knob made every fragment load conditional
         if (g.ablate == 2) return;
         const f16x8* wc = wfrag + ((long)(g.ablate == 1 ? 0 : chunk) * NSTEP + step) * 2 * 64;
+#else
+        const f16x8* wc = wfrag + ((long)chunk * NSTEP + step) * 2 * 64;
+#endif
         aH[slot] = wc[0];
         aL[slot] = wc[64];
     };
@@ -459,16 +459,20 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
 #pragma unroll
         for (int step = 0; step < NSTEP; ++step) {
             const int tap = step / KS, ks = step % KS;
-            // prefetch the fragments of step + D (possibly the next chunk's first steps)
+            // Prefetch the fragments of step + D (possibly the next chunk's first steps) and, at step 0, the next chunk's patch.  Every
+            // load is UNCONDITIONAL (the last chunk re-reads itself: L1/L2 hits) and pinned here by a scheduling barrier.  Reading the
+            // ISA of round 1's loop showed why the fragment loads cost 35-60 % (profiles/r02_conv_weight_path.md): with the loads
+            // conditional (`if (more)`) hipcc's waitcnt pass merged the paths and waited vmcnt(0) -- for the patch loads it had just
+            // issued -- and, unpinned, its scheduler sank each fragment load to one MFMA before its use; either way the two-step
+            // prefetch did not exist.  Unconditional + pinned, the waits come out counted (vmcnt(N) leaves the younger loads in flight).
+            const int cn = more ? c + 1 : c;
             if (step + D < NSTEP) load_a(c, step + D, (step + D) % R);
-            else if (more) load_a(c + 1, step + D - NSTEP, (step + D) % R);
+            else load_a(cn, step + D - NSTEP, (step + D) % R);
             if (NLW == 0 && step == 0) {
-                if (more) {
-                    if (VEC) issue_loads_v(c + 1, stgv);
-                    else issue_loads(c + 1, stg0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                if (VEC) issue_loads_v(cn, stgv);
+                else issue_loads(cn, stg0);
             }
+            __builtin_amdgcn_sched_barrier(0);
             // record offset of tap (ky, kx); stride 2 stores the patch columns de-interleaved (even columns, then odd), so column
             // 2 * txx + kx sits at txx + (kx >> 1) + (kx & 1) * pwh
             const int ky = tap / KW, kx = tap % KW;      // compile-time after unrolling
