@@ -396,10 +396,12 @@ class StackedConvLayers(Module):
         self.blocks = [ConvDropoutNormNonlin(cin, cout, first_stride if first_stride is not None else 1)] + \
                       [ConvDropoutNormNonlin(cout, cout) for _ in range(num_convs - 1)]
 
-    def forward(self, x, x2=None):
-        # A block whose output feeds only the next block of the stack leaves its InstanceNorm + LeakyReLU to that block's
-        # convolution (applied while the tile is staged, ops.conv2d_f16s_prenorm): one 8-byte-per-element pass less per pair.
-        pending = None                                   # (raw conv output, its statistics, its norm module)
+    def forward(self, x, x2=None, pending=None, defer_last=None):
+        """A block whose output feeds only the next convolution leaves its InstanceNorm + LeakyReLU to that convolution (applied while the
+        tile is staged, ops.conv2d_f16s_prenorm): one 8-byte-per-element pass less per pair.
+        pending = (raw conv output, its statistics, its norm module) handed over by the PREVIOUS stack (x is then ignored);
+        defer_last = the convolution that will consume this stack's output alone: when it qualifies, the last block's norm is handed on
+        as the returned `pending` instead of being applied.  Returns x, or (x, pending) when defer_last is given."""
         for i, b in enumerate(self.blocks):
             last = i == len(self.blocks) - 1
             if pending is not None:
@@ -411,14 +413,17 @@ class StackedConvLayers(Module):
             else:
                 kw = {} if (x2 is None or i > 0) else {"x2": x2}
                 y, ws_b = b.conv(x, stats_groups=b.instnorm.groups, **kw)
-            nxt = None if last else self.blocks[i + 1]
-            if (nxt is not None and ws_b is not None and nxt.conv.ks == (3, 3) and nxt.conv.stride == 1 and getattr(nxt.conv, "_f16s", False)
-                    and ops.prenorm_ok(y, nxt.conv.cout)):
+            nxt = defer_last if last else self.blocks[i + 1].conv
+            if (nxt is not None and ws_b is not None and nxt.ks == (3, 3) and nxt.stride == 1 and getattr(nxt, "_f16s", False)
+                    and ops.prenorm_ok(y, nxt.cout)):
                 pending = (y, ws_b, b.instnorm)
                 continue
             pending = None
             x = b.instnorm(y, act="lrelu", ws=ws_b)
-        return x
+        return (x, pending) if defer_last is not None else x
+
+    def first_conv(self):
+        return self.blocks[0].conv
 
 
 class Generic_UNet(Module):
@@ -471,12 +476,16 @@ class Generic_UNet(Module):
         for d in range(len(self.conv_blocks_context) - 1):
             x = self.conv_blocks_context[d](x)
             skips.append(x)
+        # the two stacks of the bottleneck and of every decoder stage are one chain: the first stack's norm rides into the second stack's
+        # convolution instead of running as a pass of its own
         bott = self.conv_blocks_context[-1]
-        x = bott[1](bott[0](x))
+        x, pend = bott[0](x, defer_last=bott[1].first_conv())
+        x = bott[1](x, pending=pend)
         for u in range(len(self.tu)):
             up = self.tu[u](x)
             blk = self.conv_blocks_localization[u]
-            x = blk[1](blk[0](up, x2=skips[-(u + 1)]))
+            x, pend = blk[0](up, x2=skips[-(u + 1)], defer_last=blk[1].first_conv())
+            x = blk[1](x, pending=pend)
         return self.seg_outputs[-1](x)
 
 
@@ -502,10 +511,13 @@ class StackedConvLayers3D(Module):
         self.blocks = [ConvDropoutNormNonlin3D(cin, cout, kernel, first_stride if first_stride is not None else (1, 1, 1))] + \
                       [ConvDropoutNormNonlin3D(cout, cout, kernel) for _ in range(num_convs - 1)]
 
-    def forward(self, x, x2=None):
+    def forward(self, x, x2=None, pending=None, defer_last=None):
         for i, b in enumerate(self.blocks):
             x = b(x, x2=x2) if i == 0 else b(x)
-        return x
+        return (x, None) if defer_last is not None else x        # (3-D stacks apply every norm themselves)
+
+    def first_conv(self):
+        return self.blocks[0].conv
 
 
 class Generic_UNet3D(Generic_UNet):
