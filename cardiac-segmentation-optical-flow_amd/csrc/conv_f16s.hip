@@ -86,7 +86,7 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform by construction: keep it in an SGPR
     const int half = lane >> 5, l31 = lane & 31;
     const bool loader = NLW > 0 && wave >= NW;     // wave-uniform
     const int cw = wave % NW;                       // index among the MFMA waves
