@@ -134,7 +134,15 @@ __global__ void __launch_bounds__(P7_THREADS, 3) corr_volume_p7_kernel(const flo
         int is_tile = 0, is_ch = 0;
         unsigned t_off[2];
         __amdgpu_buffer_rsrc_t rs_prev, rs_cur;
+        // Past the last tile the cursor keeps running with out-of-range offsets (the buffer loads return zeros without touching memory):
+        // every issue / write below is UNCONDITIONAL, which is what lets the compiler count the loads in flight -- with a conditional
+        // issue its s_waitcnt pass fell back to vmcnt(0) in write(), i.e. the set issued a moment ago had to land before the barrier and
+        // the three-step lead of this cursor collapsed to one exposed HBM latency per step
         auto setup = [&]() {
+            if (is_tile >= n_my) {
+                t_off[0] = t_off[1] = OOB;
+                return;
+            }
             const Tile t = decode(is_tile);
             const long sample = (long)t.b * C * HW;
             rs_prev = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(prev + sample), 0, (int)((long)C * HW4), 0x00020000);
@@ -148,7 +156,6 @@ __global__ void __launch_bounds__(P7_THREADS, 3) corr_volume_p7_kernel(const flo
         setup();
         f32x4 sa[2][P7_CC], sb[2][P7_CC];
         auto issue = [&](f32x4 (&stg)[2][P7_CC]) {
-            if (is_tile >= n_my) return;
             const unsigned c0 = (unsigned)(is_ch * P7_CC) * HW4;
 #pragma unroll
             for (int k = 0; k < 2; ++k)
@@ -160,7 +167,8 @@ __global__ void __launch_bounds__(P7_THREADS, 3) corr_volume_p7_kernel(const flo
                 }
             if (++is_ch == nchunk) {
                 is_ch = 0;
-                if (++is_tile < n_my) setup();
+                ++is_tile;
+                setup();
             }
         };
         auto write = [&](int step, const f32x4 (&stg)[2][P7_CC]) {
@@ -191,17 +199,22 @@ __global__ void __launch_bounds__(P7_THREADS, 3) corr_volume_p7_kernel(const flo
         write(0, sa);
         issue(sa);
         __syncthreads();
+        // FMA waves work on `step` (stage step&1); set B holds step+1, set A step+2
         int step = 0;
-        while (true) {
-            // FMA waves work on `step` (stage step&1); set B holds step+1, set A step+2
-            if (step + 1 < nsteps) { write(step + 1, sb); issue(sb); }
+        for (; step + 1 < nsteps; step += 2) {
+            write(step + 1, sb);
+            issue(sb);
             __syncthreads();
             tile_end(step);
-            if (++step >= nsteps) break;
-            if (step + 1 < nsteps) { write(step + 1, sa); issue(sa); }
+            write(step + 2, sa);
+            issue(sa);
+            __syncthreads();
+            tile_end(step + 1);
+        }
+        if (step < nsteps) {
+            write(step + 1, sb);
             __syncthreads();
             tile_end(step);
-            if (++step >= nsteps) break;
         }
         return;
     }
