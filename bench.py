@@ -116,6 +116,20 @@ def cpu_baseline(variant, seed, T_sample):
     from cineflow.inference import chunk_orders
     from oracle import ops as OO
     torch.set_num_threads(host_threads())
+    if variant == "warp":
+        from oracle import metrics as OMet
+        n = 512
+        flow, img, lab = synthetic_pairs(n, 256, 1234)
+        with torch.no_grad():
+            OO.warp_bilinear(flow[:2], img[:2])  # warm-up
+            t0 = time.perf_counter()
+            OO.warp_bilinear(flow, img)
+            OO.warp_labels(flow[None], lab[:, None].float())
+            for b in range(n):
+                OMet.jacobian_determinant(flow[b].permute(1, 2, 0).numpy())
+            dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "frame pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "%d frame pairs of the same workload (oracle/: grid_sample warp, one-hot label warp, np.gradient Jacobian), %.1f s" % (n, dt)}
     fnet = fill_module_(OM.SegFlowGaussian(**flow_net_kwargs(variant)), seed)
     frames = synthetic_cine(1, T_sample, 256, 1234)
     with torch.no_grad():
@@ -323,12 +337,58 @@ def bench_raft(args, dev, h, world, rank, steps, warmup):
     }
 
 
+def synthetic_pairs(B, S, seed):
+    """B frame pairs' worth of VoxelMorph inputs: a smooth displacement field (coarse 16x16 Gaussian field of sigma 3 px, bilinearly
+    upsampled -- cardiac motion is a few pixels and smooth), a moving image and an ED label map with the four classes as nested discs"""
+    g = torch.Generator().manual_seed(seed)
+    coarse = 3.0 * torch.randn(B, 2, 16, 16, generator=g)
+    flow = torch.nn.functional.interpolate(coarse, size=(S, S), mode="bilinear", align_corners=True).contiguous()
+    img = synthetic_cine(B, 1, S, seed + 1)[0].reshape(B, 1, S, S).contiguous()
+    yy, xx = torch.meshgrid(torch.arange(S, dtype=torch.float32), torch.arange(S, dtype=torch.float32), indexing="ij")
+    c = S / 2 + 8.0 * torch.randn(B, 2, generator=g)
+    r = torch.sqrt((yy[None] - c[:, 0, None, None]) ** 2 + (xx[None] - c[:, 1, None, None]) ** 2)
+    lab = ((r < 0.30 * S).to(torch.uint8) + (r < 0.20 * S).to(torch.uint8) + (r < 0.12 * S).to(torch.uint8)).contiguous()
+    return flow, img, lab
+
+
+def bench_warp(args, dev, h, world, rank, steps, warmup):
+    """BASELINE config 1: the VoxelMorph warp of 256x256 frame pairs as voxelmorph_saver_* / compute_jacobian use it; a step = B pairs:
+    SpatialTransformer on the moving image, warp_linear label propagation (one-hot -> warp -> argmax), Jacobian determinant"""
+    from cineflow import ops
+    B, S = args.pairs, 256
+    flow, img, lab = (t.to(dev) for t in synthetic_pairs(B, S, 4321 + rank))
+    fl5 = flow[None]
+    log("warp: inputs resident (rank %d/%d, B=%d pairs)" % (rank, world, B))
+
+    def step():
+        return ops.warp_bilinear(flow, img), ops.warp_labels(fl5, lab), ops.jacobian_det(flow)
+
+    dt = timed(step, steps, warmup, h, dev, "warp")
+    recs = [read_profile(h, k) for k in (11, 12, 13)]
+    h.cf_profile_enable(0)
+    names = ["warp_bilinear_2d_v4_kernel (flow 8 B + image 4 B read, 4 B written per pixel)",
+             "warp_labels_2d_v4_kernel (flow 8 B + label 1 B read, 1 B written per pixel)",
+             "jacobian_det_2d_v4_kernel (displacement 8 B read, float64 determinant 8 B written per pixel)"]
+    roofs = [hbm_roofline(n, r) for n, r in zip(names, recs)]
+    dom = max(range(3), key=lambda i: recs[i][0])
+    pairs = world * B * steps
+    return {
+        "metric": "VoxelMorph warp frame pairs/sec at 256x256", "value": round(pairs / dt, 1), "unit": "frame pairs/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 (Jacobian f64)", "data": "synthetic",
+        "config": {"workload": "BASELINE config 1: per 256x256 frame pair, SpatialTransformer warp of the moving image, warp_linear label "
+                               "propagation (4 classes) and the Jacobian determinant of the displacement", "pairs_per_step_per_gpu": B,
+                   "image": "256x256"},
+        "roofline": roofs[dom], "roofline_other": [r for i, r in enumerate(roofs) if i != dom],
+    }
+
+
 def dry_run(args, world, rank):
     """gloo + CPU tensors: launch, rendezvous, flat weight broadcast, shard seeding, barrier and max-over-ranks exactly as in
     the measured path; the GPU step is a sleep.  No libcineflow_hip.so call (there is no GPU to make one on)."""
     from cineflow import parallel
     dev = torch.device("cpu")
-    nets = load_nets(make_nets(args.variant, with_seg=args.variant != "raft"), dev, 1234, world, rank)
+    nets = [] if args.variant == "warp" else load_nets(make_nets(args.variant, with_seg=args.variant != "raft"), dev, 1234, world, rank)
     sums = [n._dry_checksum for n in nets]
     frames = synthetic_cine(2, 4, 64, 1234 + rank)
     parallel.barrier()
@@ -354,15 +414,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slices", type=int, default=32, help="cine slices per step and per GPU (B)")
     ap.add_argument("--frames", type=int, default=30, help="frames per cine slice (T)")
-    ap.add_argument("--pairs", type=int, default=64, help="frame pairs per RAFT step and per GPU")
-    ap.add_argument("--variant", default="video", choices=["video", "raft_config", "raft"],
-                    help="video / raft_config: BASELINE config 4 with that flow dispatch; raft: BASELINE config 3 as the headline line")
+    ap.add_argument("--pairs", type=int, default=None, help="frame pairs per step and per GPU (default: 64 for raft, 960 for warp)")
+    ap.add_argument("--variant", default="video", choices=["video", "raft_config", "raft", "warp"],
+                    help="video / raft_config: BASELINE config 4 with that flow dispatch; raft: BASELINE config 3 as the headline line; "
+                         "warp: BASELINE config 1 (VoxelMorph warp of frame pairs)")
     ap.add_argument("--no-raft", action="store_true", help="skip the nested BASELINE config 3 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", default="f16s", choices=["f16s", "f32"], help="f16s: f16-MFMA hi/lo split (default); f32: exact fp32 MFMA")
     ap.add_argument("--cpu-frames", type=int, default=5)
     ap.add_argument("--dry-run", action="store_true", help="exercise the multi-rank path on gloo / CPU tensors without GPU work")
     args = ap.parse_args()
+    if args.pairs is None:
+        args.pairs = 960 if args.variant == "warp" else 64
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))           # before any GPU call in this process
@@ -388,6 +451,8 @@ def main():
 
     if args.variant == "raft":
         line = bench_raft(args, dev, h, world, rank, args.steps, args.warmup)
+    elif args.variant == "warp":
+        line = bench_warp(args, dev, h, world, rank, args.steps, args.warmup)
     else:
         line = bench_joint(args, dev, h, world, rank)
         if not args.no_raft:

@@ -70,8 +70,10 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // Sampling coordinate of SpatialTransformer.forward (integration.py:61-79) followed by
 // grid_sample's align_corners=True un-normalisation, with the reference's fp32 rounding path:
 //   g = 2 * ((i + f) / (S - 1) - 0.5);  pos = ((g + 1) / 2) * (S - 1)
-// Contraction into FMAs is prevented so that every intermediate rounds as in PyTorch.
+// Contraction into FMAs is switched off (hipcc's default is -ffp-contract=fast and __fadd_rn / __fmul_rn are plain operators in its
+// headers) so that every intermediate rounds as in PyTorch.
 __device__ __forceinline__ float st_coord(float idx, float f, float size_m1) {
+#pragma clang fp contract(off)
     float loc = __fadd_rn(idx, f);
     float g = __fmul_rn(2.0f, __fsub_rn(__fdiv_rn(loc, size_m1), 0.5f));
     return __fmul_rn(__fdiv_rn(__fadd_rn(g, 1.0f), 2.0f), size_m1);
@@ -85,6 +87,7 @@ struct Taps {
 };
 
 __device__ __forceinline__ Taps make_taps(float y, float x, int H, int W) {
+#pragma clang fp contract(off)
     Taps t;
     float yf = floorf(y), xf = floorf(x);
     float wy = __fsub_rn(y, yf), wx = __fsub_rn(x, xf);
@@ -109,6 +112,7 @@ __device__ __forceinline__ Taps make_taps(float y, float x, int H, int W) {
 }
 
 __device__ __forceinline__ float sample_taps(const float* __restrict__ plane, const Taps& t, int W) {
+#pragma clang fp contract(off)
     const float* p = plane + (long)t.y0 * W + t.x0;
     float a = t.v00 ? p[0] : 0.f;
     float b = t.v01 ? p[1] : 0.f;

@@ -16,7 +16,8 @@ enum ProfileKernel {
     PK_CORR_LOOKUP = 8,                                      // RAFT correlation lookup; work = algorithmic bytes
     PK_CONVEX_UP = 9,                                        // RAFT convex upsampling; work = algorithmic bytes
     PK_GN_APPLY = 10,                                        // GroupNorm apply passes; work = algorithmic bytes
-    PK_COUNT = 11
+    PK_WARP = 11, PK_WARP_LABELS = 12, PK_JACOBIAN = 13,     // VoxelMorph warp family (2-D); work = algorithmic bytes
+    PK_COUNT = 14
 };
 
 bool profile_on();

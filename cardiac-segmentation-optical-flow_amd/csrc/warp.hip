@@ -2,6 +2,10 @@
 // fused memory-encoder input, Jacobian determinant.  All HBM-bound: one thread per output pixel, flow read
 // once (coalesced along W), the four taps served by L1/L2 (neighbouring lanes sample neighbouring pixels).
 #include "common.h"
+#include "profile.h"
+
+// every product and sum below rounds on its own, as in ATen / numpy (hipcc would otherwise contract a * b + c into one FMA)
+#pragma clang fp contract(off)
 
 namespace cf {
 
@@ -114,6 +118,117 @@ __global__ void __launch_bounds__(256) jacobian_det_2d_kernel(const float* __res
 }
 
 
+// ---------------------------------------------------------------------------------------------------------- W % 4 == 0 forms
+// Four consecutive pixels of one row per thread: the flow is read as two 16-byte loads, the outputs leave as one 16-byte (float) /
+// 4-byte (label) / 2 x 16-byte (double) store, and the sixteen tap gathers of a thread are independent loads in flight together.
+// The arithmetic per pixel is the scalar kernels' (same helpers, same order): results are bit-identical.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+template <bool ADD>
+__global__ void __launch_bounds__(256) warp_bilinear_2d_v4_kernel(const float* __restrict__ flow, const float* __restrict__ src,
+                                                                  float* __restrict__ out, int B, int C, int H, int W,
+                                                                  const float* __restrict__ addend) {
+    const long HW = (long)H * W;
+    const long nq = (long)B * HW / 4;
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+        const long e = q * 4;
+        const int b = (int)(e / HW);
+        const int p = (int)(e - (long)b * HW);
+        const int i = p / W, j = p - i * W;
+        const float* fb = flow + (long)b * 2 * HW;
+        const f32x4 fy = *reinterpret_cast<const f32x4*>(fb + p);
+        const f32x4 fx = *reinterpret_cast<const f32x4*>(fb + HW + p);
+        Taps t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            t[k] = make_taps(st_coord((float)i, fy[k], (float)(H - 1)), st_coord((float)(j + k), fx[k], (float)(W - 1)), H, W);
+        const float* sb = src + (long)b * C * HW;
+        const long ob = (long)b * C * HW + p;
+        for (int c = 0; c < C; ++c) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = sample_taps(sb + (long)c * HW, t[k], W);
+            if (ADD) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(addend + ob + (long)c * HW);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = __fadd_rn(a[k], v[k]);
+            }
+            *reinterpret_cast<f32x4*>(out + ob + (long)c * HW) = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) warp_labels_2d_v4_kernel(const float* __restrict__ flow, const uint8_t* __restrict__ labels,
+                                                                uint8_t* __restrict__ out, int T, int B, int K, int H, int W) {
+    const long HW = (long)H * W;
+    const long nq = (long)T * B * HW / 4;
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+        const long e = q * 4;
+        const long tb = e / HW;
+        const int p = (int)(e - tb * HW);
+        const int b = (int)(tb % B);
+        const int i = p / W, j = p - i * W;
+        const float* fb = flow + tb * 2 * HW;
+        const f32x4 fy = *reinterpret_cast<const f32x4*>(fb + p);
+        const f32x4 fx = *reinterpret_cast<const f32x4*>(fb + HW + p);
+        unsigned packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const Taps t = make_taps(st_coord((float)i, fy[k], (float)(H - 1)), st_coord((float)(j + k), fx[k], (float)(W - 1)), H, W);
+            const uint8_t* lb = labels + (long)b * HW + (long)t.y0 * W + t.x0;
+            const int l00 = t.v00 ? lb[0] : -1, l01 = t.v01 ? lb[1] : -1, l10 = t.v10 ? lb[W] : -1, l11 = t.v11 ? lb[W + 1] : -1;
+            float best = -1.f;
+            int arg = 0;
+            for (int c = 0; c < K; ++c) {
+                const float v = __fadd_rn(__fadd_rn(__fadd_rn(l00 == c ? t.w00 : 0.f, l01 == c ? t.w01 : 0.f), l10 == c ? t.w10 : 0.f),
+                                          l11 == c ? t.w11 : 0.f);
+                if (v > best) { best = v; arg = c; }
+            }
+            packed |= (unsigned)arg << (8 * k);
+        }
+        *reinterpret_cast<unsigned*>(out + e) = packed;
+    }
+}
+
+__global__ void __launch_bounds__(256) jacobian_det_2d_v4_kernel(const float* __restrict__ disp, double* __restrict__ det, int B, int H,
+                                                                 int W) {
+    const long HW = (long)H * W;
+    const long nq = (long)B * HW / 4;
+    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
+        const long e = q * 4;
+        const int b = (int)(e / HW);
+        const int p = (int)(e - (long)b * HW);
+        const int i = p / W, j = p - i * W;
+        const float* d0 = disp + (long)b * 2 * HW;
+        const float* d1 = d0 + HW;
+        const int iu = i > 0 ? i - 1 : i, id = i < H - 1 ? i + 1 : i;
+        const double hi = (double)(id - iu);
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(d0 + iu * W + j), n0 = *reinterpret_cast<const f32x4*>(d0 + id * W + j);
+        const f32x4 u1 = *reinterpret_cast<const f32x4*>(d1 + iu * W + j), n1 = *reinterpret_cast<const f32x4*>(d1 + id * W + j);
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(d0 + i * W + j), c1 = *reinterpret_cast<const f32x4*>(d1 + i * W + j);
+        // row i, columns j-1 .. j+4 (the ends clamp to the row like np.gradient's one-sided differences)
+        const int jm = j > 0 ? j - 1 : 0, jp = j + 4 < W ? j + 4 : W - 1;
+        const float r0[6] = {d0[i * W + jm], c0[0], c0[1], c0[2], c0[3], d0[i * W + jp]};
+        const float r1[6] = {d1[i * W + jm], c1[0], c1[1], c1[2], c1[3], d1[i * W + jp]};
+        double o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int jj = j + k;
+            const int jl = jj > 0 ? jj - 1 : jj, jr = jj < W - 1 ? jj + 1 : jj;
+            const double hj = (double)(jr - jl);
+            const double p0_a0 = (((double)n0[k] + id) - ((double)u0[k] + iu)) / hi;
+            const double p1_a0 = (((double)n1[k] + jj) - ((double)u1[k] + jj)) / hi;
+            // element jl / jr of the row through the 6-wide window (index jl - (j - 1))
+            const double p0_a1 = (((double)r0[jr - j + 1] + i) - ((double)r0[jl - j + 1] + i)) / hj;
+            const double p1_a1 = (((double)r1[jr - j + 1] + jr) - ((double)r1[jl - j + 1] + jl)) / hj;
+            o[k] = p0_a0 * p1_a1 - p0_a1 * p1_a0;
+        }
+        *reinterpret_cast<f64x2*>(det + e) = f64x2{o[0], o[1]};
+        *reinterpret_cast<f64x2*>(det + e + 2) = f64x2{o[2], o[3]};
+    }
+}
+
 // 3-D branch of SpatialTransformer (integration.py:75-77): trilinear, align_corners=True, zeros outside.  Weights and the
 // accumulation order follow ATen's scalar grid_sampler_3d ((x1 - ix) * (y1 - iy) * (z1 - iz), corners tnw, tne, tsw, tse,
 // bnw, bne, bsw, bse).  flow channel i displaces along axis i of (D, H, W).
@@ -202,13 +317,24 @@ __global__ void __launch_bounds__(256) jacobian_det_3d_kernel(const float* __res
 
 using namespace cf;
 
+// CF_WARP_SCALAR=1: one-pixel-per-thread kernels also for W % 4 == 0 (A/B knob)
+static bool warp_v4(int W) {
+    static const bool scalar = [] { const char* e = getenv("CF_WARP_SCALAR"); return e && e[0] == '1'; }();
+    return W % 4 == 0 && !scalar;
+}
+
 extern "C" int cf_warp_bilinear_2d(const float* flow, const float* src, float* out, int B, int C, int H, int W, void* stream) {
     CF_REQUIRE(flow && src && out, "null pointer");
     CF_REQUIRE(B > 0 && C > 0 && H > 1 && W > 1, "bad shape B=%d C=%d H=%d W=%d", B, C, H, W);
     CF_REQUIRE(out != src, "out must not alias src");
     long n = (long)B * H * W;
-    hipLaunchKernelGGL(warp_bilinear_2d_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, as_stream(stream), flow, src, out, B, C,
-                       H, W, 0.f, (const float*)nullptr);
+    const double bytes = 4.0 * n * (2.0 + 2.0 * C);   // flow + src read once, out written once
+    if (warp_v4(W))
+        launch_profiled(PK_WARP, bytes, warp_bilinear_2d_v4_kernel<false>, dim3(flat_grid(n / 4, 256)), dim3(256), as_stream(stream), flow,
+                        src, out, B, C, H, W, (const float*)nullptr);
+    else
+        launch_profiled(PK_WARP, bytes, warp_bilinear_2d_kernel, dim3(flat_grid(n, 256)), dim3(256), as_stream(stream), flow, src, out, B, C,
+                        H, W, 0.f, (const float*)nullptr);
     CF_CHECK_LAUNCH();
     return CF_OK;
 }
@@ -226,8 +352,12 @@ extern "C" int cf_vecint_2d(const float* vec, float* out, float* tmp, int B, int
     CF_CHECK_LAUNCH();
     long np = (long)B * H * W;
     for (int it = 0; it < nsteps; ++it) {
-        hipLaunchKernelGGL(warp_bilinear_2d_kernel, dim3(flat_grid(np, 256)), dim3(256), 0, s, cur, cur, nxt, B, 2, H, W, 1.f,
-                           (const float*)cur);
+        if (warp_v4(W))
+            hipLaunchKernelGGL(warp_bilinear_2d_v4_kernel<true>, dim3(flat_grid(np / 4, 256)), dim3(256), 0, s, cur, cur, nxt, B, 2, H, W,
+                               (const float*)cur);
+        else
+            hipLaunchKernelGGL(warp_bilinear_2d_kernel, dim3(flat_grid(np, 256)), dim3(256), 0, s, cur, cur, nxt, B, 2, H, W, 1.f,
+                               (const float*)cur);
         CF_CHECK_LAUNCH();
         float* t = cur; cur = nxt; nxt = t;
     }
@@ -239,8 +369,13 @@ extern "C" int cf_warp_labels_2d(const float* flow, const uint8_t* labels, uint8
     CF_REQUIRE(flow && labels && out, "null pointer");
     CF_REQUIRE(T > 0 && B > 0 && K > 0 && K <= 8 && H > 1 && W > 1, "bad shape");
     long n = (long)T * B * H * W;
-    hipLaunchKernelGGL(warp_labels_2d_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, as_stream(stream), flow, labels, out, T, B,
-                       K, H, W);
+    const double bytes = 10.0 * n;   // flow read (8 B), one label gathered (1 B) and one written (1 B) per pixel
+    if (warp_v4(W))
+        launch_profiled(PK_WARP_LABELS, bytes, warp_labels_2d_v4_kernel, dim3(flat_grid(n / 4, 256)), dim3(256), as_stream(stream), flow,
+                        labels, out, T, B, K, H, W);
+    else
+        launch_profiled(PK_WARP_LABELS, bytes, warp_labels_2d_kernel, dim3(flat_grid(n, 256)), dim3(256), as_stream(stream), flow, labels,
+                        out, T, B, K, H, W);
     CF_CHECK_LAUNCH();
     return CF_OK;
 }
@@ -258,7 +393,12 @@ extern "C" int cf_jacobian_det_2d(const float* disp, double* det, int B, int H, 
     CF_REQUIRE(disp && det, "null pointer");
     CF_REQUIRE(B > 0 && H >= 2 && W >= 2, "bad shape");
     long n = (long)B * H * W;
-    hipLaunchKernelGGL(jacobian_det_2d_kernel, dim3(flat_grid(n, 256)), dim3(256), 0, as_stream(stream), disp, det, B, H, W);
+    const double bytes = 16.0 * n;   // displacement read (8 B), determinant written (8 B, float64 like numpy)
+    if (warp_v4(W))
+        launch_profiled(PK_JACOBIAN, bytes, jacobian_det_2d_v4_kernel, dim3(flat_grid(n / 4, 256)), dim3(256), as_stream(stream), disp, det, B,
+                        H, W);
+    else
+        launch_profiled(PK_JACOBIAN, bytes, jacobian_det_2d_kernel, dim3(flat_grid(n, 256)), dim3(256), as_stream(stream), disp, det, B, H, W);
     CF_CHECK_LAUNCH();
     return CF_OK;
 }

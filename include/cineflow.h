@@ -332,7 +332,8 @@ int cf_sample_points_2d(const float* field, const float* pts, float* out, int B,
  * brackets exactly that kernel on its own stream (hipExtLaunchKernelGGL); 0 disables.  Kernel ids:
  * 0,1,2 = conv_igemm MT 1,2,4 (work = flops); 3,4,5 = corr_volume_p7 stride 1,2,4 (work = algorithmic bytes);
  * 6 = conv_f16s (work = flops); 7 = RAFT all-pairs volume + pyramid pooling, 8 = RAFT correlation lookup, 9 = convex
- * upsampling, 10 = GroupNorm apply passes (work = algorithmic bytes).
+ * upsampling, 10 = GroupNorm apply passes, 11 = 2-D bilinear warp, 12 = 2-D label warp, 13 = 2-D Jacobian determinant (work =
+ * algorithmic bytes).
  * cf_profile_read sums kernel durations [ms], work and launches since the last cf_profile_reset (it synchronises: call it
  * outside the timed region). */
 int cf_profile_enable(int max_launches);
