@@ -121,68 +121,100 @@ __global__ void __launch_bounds__(256) jacobian_det_2d_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------------------- W % 4 == 0 forms
 // Four consecutive pixels of one row per thread: the flow is read as two 16-byte loads, the outputs leave as one 16-byte (float) /
 // 4-byte (label) / 2 x 16-byte (double) store, and the sixteen tap gathers of a thread are independent loads in flight together.
+// The taps go through a buffer resource over the whole source tensor: a tap outside the image gets an out-of-range offset and the
+// hardware returns 0 for it -- no branch and no 64-bit address per tap (the one-pixel kernels spend more instructions on those than on
+// the interpolation).  Index arithmetic is 32-bit; the entry points send tensors that do not fit (>= 2 GiB) to the one-pixel kernels.
 // The arithmetic per pixel is the scalar kernels' (same helpers, same order): results are bit-identical.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned TAP_OOB = 0x80000000u;
 
 template <bool ADD>
 __global__ void __launch_bounds__(256) warp_bilinear_2d_v4_kernel(const float* __restrict__ flow, const float* __restrict__ src,
                                                                   float* __restrict__ out, int B, int C, int H, int W,
                                                                   const float* __restrict__ addend) {
-    const long HW = (long)H * W;
-    const long nq = (long)B * HW / 4;
-    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
-        const long e = q * 4;
-        const int b = (int)(e / HW);
-        const int p = (int)(e - (long)b * HW);
-        const int i = p / W, j = p - i * W;
-        const float* fb = flow + (long)b * 2 * HW;
-        const f32x4 fy = *reinterpret_cast<const f32x4*>(fb + p);
-        const f32x4 fx = *reinterpret_cast<const f32x4*>(fb + HW + p);
-        Taps t[4];
+    const unsigned HW = (unsigned)(H * W);
+    const unsigned nq = (unsigned)B * HW / 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)((unsigned)B * C * HW * 4u), 0x00020000);
+    for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        const unsigned e = q * 4;
+        const unsigned b = e / HW;
+        const unsigned p = e - b * HW;
+        const unsigned i = p / (unsigned)W, j = p - i * (unsigned)W;
+        const float* fb = flow + (size_t)b * 2 * HW + p;
+        const f32x4 fy = *reinterpret_cast<const f32x4*>(fb);
+        const f32x4 fx = *reinterpret_cast<const f32x4*>(fb + HW);
+        unsigned off[4][4];
+        float w[4][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            t[k] = make_taps(st_coord((float)i, fy[k], (float)(H - 1)), st_coord((float)(j + k), fx[k], (float)(W - 1)), H, W);
-        const float* sb = src + (long)b * C * HW;
-        const long ob = (long)b * C * HW + p;
+        for (int k = 0; k < 4; ++k) {
+            const Taps t = make_taps(st_coord((float)i, fy[k], (float)(H - 1)), st_coord((float)(j + k), fx[k], (float)(W - 1)), H, W);
+            const unsigned base = ((unsigned)((int)(b * C * HW) + t.y0 * W + t.x0)) * 4u;
+            off[k][0] = t.v00 ? base : TAP_OOB;
+            off[k][1] = t.v01 ? base + 4u : TAP_OOB;
+            off[k][2] = t.v10 ? base + 4u * W : TAP_OOB;
+            off[k][3] = t.v11 ? base + 4u * W + 4u : TAP_OOB;
+            w[k][0] = t.w00; w[k][1] = t.w01; w[k][2] = t.w10; w[k][3] = t.w11;
+        }
+        const size_t ob = (size_t)b * C * HW + p;
         for (int c = 0; c < C; ++c) {
+            const unsigned soff = (unsigned)c * HW * 4u;
+            float g[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) g[k][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off[k][n], soff, 0));
             f32x4 v;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = sample_taps(sb + (long)c * HW, t[k], W);
+            for (int k = 0; k < 4; ++k)   // sample_taps' association: nw*w + ne*w + sw*w + se*w
+                v[k] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(g[k][0], w[k][0]), __fmul_rn(g[k][1], w[k][1])), __fmul_rn(g[k][2], w[k][2])),
+                                 __fmul_rn(g[k][3], w[k][3]));
             if (ADD) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(addend + ob + (long)c * HW);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(addend + ob + (size_t)c * HW);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = __fadd_rn(a[k], v[k]);
             }
-            *reinterpret_cast<f32x4*>(out + ob + (long)c * HW) = v;
+            *reinterpret_cast<f32x4*>(out + ob + (size_t)c * HW) = v;
         }
     }
 }
 
 __global__ void __launch_bounds__(256) warp_labels_2d_v4_kernel(const float* __restrict__ flow, const uint8_t* __restrict__ labels,
                                                                 uint8_t* __restrict__ out, int T, int B, int K, int H, int W) {
-    const long HW = (long)H * W;
-    const long nq = (long)T * B * HW / 4;
-    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
-        const long e = q * 4;
-        const long tb = e / HW;
-        const int p = (int)(e - tb * HW);
-        const int b = (int)(tb % B);
-        const int i = p / W, j = p - i * W;
-        const float* fb = flow + tb * 2 * HW;
-        const f32x4 fy = *reinterpret_cast<const f32x4*>(fb + p);
-        const f32x4 fx = *reinterpret_cast<const f32x4*>(fb + HW + p);
-        unsigned packed = 0;
+    const unsigned HW = (unsigned)(H * W);
+    const unsigned nq = (unsigned)T * B * HW / 4;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(labels), 0, (int)((unsigned)B * HW), 0x00020000);
+    for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        const unsigned e = q * 4;
+        const unsigned tb = e / HW;
+        const unsigned p = e - tb * HW;
+        const unsigned b = tb % (unsigned)B;
+        const unsigned i = p / (unsigned)W, j = p - i * (unsigned)W;
+        const float* fb = flow + (size_t)tb * 2 * HW + p;
+        const f32x4 fy = *reinterpret_cast<const f32x4*>(fb);
+        const f32x4 fx = *reinterpret_cast<const f32x4*>(fb + HW);
+        int lab[4][4];
+        float w[4][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const Taps t = make_taps(st_coord((float)i, fy[k], (float)(H - 1)), st_coord((float)(j + k), fx[k], (float)(W - 1)), H, W);
-            const uint8_t* lb = labels + (long)b * HW + (long)t.y0 * W + t.x0;
-            const int l00 = t.v00 ? lb[0] : -1, l01 = t.v01 ? lb[1] : -1, l10 = t.v10 ? lb[W] : -1, l11 = t.v11 ? lb[W + 1] : -1;
+            const unsigned base = (unsigned)((int)(b * HW) + t.y0 * W + t.x0);
+            // a tap outside the image reads 0 through the out-of-range offset; its weight is zeroed instead of its label being set to
+            // "no class" (the class sums are the same: + 0.f either way)
+            lab[k][0] = __builtin_amdgcn_raw_buffer_load_b8(rs, t.v00 ? base : TAP_OOB, 0, 0);
+            lab[k][1] = __builtin_amdgcn_raw_buffer_load_b8(rs, t.v01 ? base + 1u : TAP_OOB, 0, 0);
+            lab[k][2] = __builtin_amdgcn_raw_buffer_load_b8(rs, t.v10 ? base + W : TAP_OOB, 0, 0);
+            lab[k][3] = __builtin_amdgcn_raw_buffer_load_b8(rs, t.v11 ? base + W + 1u : TAP_OOB, 0, 0);
+            w[k][0] = t.v00 ? t.w00 : 0.f; w[k][1] = t.v01 ? t.w01 : 0.f; w[k][2] = t.v10 ? t.w10 : 0.f; w[k][3] = t.v11 ? t.w11 : 0.f;
+        }
+        unsigned packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
             float best = -1.f;
             int arg = 0;
             for (int c = 0; c < K; ++c) {
-                const float v = __fadd_rn(__fadd_rn(__fadd_rn(l00 == c ? t.w00 : 0.f, l01 == c ? t.w01 : 0.f), l10 == c ? t.w10 : 0.f),
-                                          l11 == c ? t.w11 : 0.f);
+                const float v = __fadd_rn(__fadd_rn(__fadd_rn(lab[k][0] == c ? w[k][0] : 0.f, lab[k][1] == c ? w[k][1] : 0.f),
+                                                    lab[k][2] == c ? w[k][2] : 0.f), lab[k][3] == c ? w[k][3] : 0.f);
                 if (v > best) { best = v; arg = c; }
             }
             packed |= (unsigned)arg << (8 * k);
@@ -191,37 +223,39 @@ __global__ void __launch_bounds__(256) warp_labels_2d_v4_kernel(const float* __r
     }
 }
 
+// np.gradient spacings are 1 (one-sided, at the border) or 2 (central): the division becomes a multiplication by 1.0 or 0.5, which is
+// exact and therefore the same double; an IEEE float64 division costs more than the rest of the pixel.
 __global__ void __launch_bounds__(256) jacobian_det_2d_v4_kernel(const float* __restrict__ disp, double* __restrict__ det, int B, int H,
                                                                  int W) {
-    const long HW = (long)H * W;
-    const long nq = (long)B * HW / 4;
-    for (long q = blockIdx.x * (long)blockDim.x + threadIdx.x; q < nq; q += (long)gridDim.x * blockDim.x) {
-        const long e = q * 4;
-        const int b = (int)(e / HW);
-        const int p = (int)(e - (long)b * HW);
-        const int i = p / W, j = p - i * W;
-        const float* d0 = disp + (long)b * 2 * HW;
+    const unsigned HW = (unsigned)(H * W);
+    const unsigned nq = (unsigned)B * HW / 4;
+    for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        const unsigned e = q * 4;
+        const unsigned b = e / HW;
+        const unsigned p = e - b * HW;
+        const int i = (int)(p / (unsigned)W), j = (int)(p - (unsigned)i * (unsigned)W);
+        const float* d0 = disp + (size_t)b * 2 * HW;
         const float* d1 = d0 + HW;
         const int iu = i > 0 ? i - 1 : i, id = i < H - 1 ? i + 1 : i;
-        const double hi = (double)(id - iu);
+        const double rhi = id - iu == 2 ? 0.5 : 1.0;
         const f32x4 u0 = *reinterpret_cast<const f32x4*>(d0 + iu * W + j), n0 = *reinterpret_cast<const f32x4*>(d0 + id * W + j);
         const f32x4 u1 = *reinterpret_cast<const f32x4*>(d1 + iu * W + j), n1 = *reinterpret_cast<const f32x4*>(d1 + id * W + j);
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(d0 + i * W + j), c1 = *reinterpret_cast<const f32x4*>(d1 + i * W + j);
-        // row i, columns j-1 .. j+4 (the ends clamp to the row like np.gradient's one-sided differences)
-        const int jm = j > 0 ? j - 1 : 0, jp = j + 4 < W ? j + 4 : W - 1;
-        const float r0[6] = {d0[i * W + jm], c0[0], c0[1], c0[2], c0[3], d0[i * W + jp]};
-        const float r1[6] = {d1[i * W + jm], c1[0], c1[1], c1[2], c1[3], d1[i * W + jp]};
+        // row i, columns j-1 .. j+4; at the row ends np.gradient differences the border element with its inner neighbour
+        const bool first = j == 0, last = j + 4 == W;
+        const float r0[6] = {first ? c0[0] : d0[i * W + j - 1], c0[0], c0[1], c0[2], c0[3], last ? c0[3] : d0[i * W + j + 4]};
+        const float r1[6] = {first ? c1[0] : d1[i * W + j - 1], c1[0], c1[1], c1[2], c1[3], last ? c1[3] : d1[i * W + j + 4]};
         double o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int jj = j + k;
-            const int jl = jj > 0 ? jj - 1 : jj, jr = jj < W - 1 ? jj + 1 : jj;
-            const double hj = (double)(jr - jl);
-            const double p0_a0 = (((double)n0[k] + id) - ((double)u0[k] + iu)) / hi;
-            const double p1_a0 = (((double)n1[k] + jj) - ((double)u1[k] + jj)) / hi;
-            // element jl / jr of the row through the 6-wide window (index jl - (j - 1))
-            const double p0_a1 = (((double)r0[jr - j + 1] + i) - ((double)r0[jl - j + 1] + i)) / hj;
-            const double p1_a1 = (((double)r1[jr - j + 1] + jr) - ((double)r1[jl - j + 1] + jl)) / hj;
+            const bool one_l = k == 0 && first, one_r = k == 3 && last;   // one-sided difference
+            const int jl = one_l ? jj : jj - 1, jr = one_r ? jj : jj + 1;
+            const double rhj = (one_l || one_r) ? 1.0 : 0.5;
+            const double p0_a0 = (((double)n0[k] + id) - ((double)u0[k] + iu)) * rhi;
+            const double p1_a0 = (((double)n1[k] + jj) - ((double)u1[k] + jj)) * rhi;
+            const double p0_a1 = (((double)r0[k + 2] + i) - ((double)r0[k] + i)) * rhj;
+            const double p1_a1 = (((double)r1[k + 2] + jr) - ((double)r1[k] + jl)) * rhj;
             o[k] = p0_a0 * p1_a1 - p0_a1 * p1_a0;
         }
         *reinterpret_cast<f64x2*>(det + e) = f64x2{o[0], o[1]};
@@ -318,9 +352,9 @@ __global__ void __launch_bounds__(256) jacobian_det_3d_kernel(const float* __res
 using namespace cf;
 
 // CF_WARP_SCALAR=1: one-pixel-per-thread kernels also for W % 4 == 0 (A/B knob)
-static bool warp_v4(int W) {
+static bool warp_v4(int W, double max_tensor_bytes) {
     static const bool scalar = [] { const char* e = getenv("CF_WARP_SCALAR"); return e && e[0] == '1'; }();
-    return W % 4 == 0 && !scalar;
+    return W % 4 == 0 && !scalar && max_tensor_bytes < 2147483648.0;   // 32-bit indices and buffer offsets inside the four-pixel kernels
 }
 
 extern "C" int cf_warp_bilinear_2d(const float* flow, const float* src, float* out, int B, int C, int H, int W, void* stream) {
@@ -329,7 +363,7 @@ extern "C" int cf_warp_bilinear_2d(const float* flow, const float* src, float* o
     CF_REQUIRE(out != src, "out must not alias src");
     long n = (long)B * H * W;
     const double bytes = 4.0 * n * (2.0 + 2.0 * C);   // flow + src read once, out written once
-    if (warp_v4(W))
+    if (warp_v4(W, 4.0 * n * (C > 2 ? C : 2)))
         launch_profiled(PK_WARP, bytes, warp_bilinear_2d_v4_kernel<false>, dim3(flat_grid(n / 4, 256)), dim3(256), as_stream(stream), flow,
                         src, out, B, C, H, W, (const float*)nullptr);
     else
@@ -352,7 +386,7 @@ extern "C" int cf_vecint_2d(const float* vec, float* out, float* tmp, int B, int
     CF_CHECK_LAUNCH();
     long np = (long)B * H * W;
     for (int it = 0; it < nsteps; ++it) {
-        if (warp_v4(W))
+        if (warp_v4(W, 8.0 * np))
             hipLaunchKernelGGL(warp_bilinear_2d_v4_kernel<true>, dim3(flat_grid(np / 4, 256)), dim3(256), 0, s, cur, cur, nxt, B, 2, H, W,
                                (const float*)cur);
         else
@@ -370,7 +404,7 @@ extern "C" int cf_warp_labels_2d(const float* flow, const uint8_t* labels, uint8
     CF_REQUIRE(T > 0 && B > 0 && K > 0 && K <= 8 && H > 1 && W > 1, "bad shape");
     long n = (long)T * B * H * W;
     const double bytes = 10.0 * n;   // flow read (8 B), one label gathered (1 B) and one written (1 B) per pixel
-    if (warp_v4(W))
+    if (warp_v4(W, 8.0 * n))
         launch_profiled(PK_WARP_LABELS, bytes, warp_labels_2d_v4_kernel, dim3(flat_grid(n / 4, 256)), dim3(256), as_stream(stream), flow,
                         labels, out, T, B, K, H, W);
     else
@@ -394,7 +428,7 @@ extern "C" int cf_jacobian_det_2d(const float* disp, double* det, int B, int H, 
     CF_REQUIRE(B > 0 && H >= 2 && W >= 2, "bad shape");
     long n = (long)B * H * W;
     const double bytes = 16.0 * n;   // displacement read (8 B), determinant written (8 B, float64 like numpy)
-    if (warp_v4(W))
+    if (warp_v4(W, 8.0 * n))
         launch_profiled(PK_JACOBIAN, bytes, jacobian_det_2d_v4_kernel, dim3(flat_grid(n / 4, 256)), dim3(256), as_stream(stream), disp, det, B,
                         H, W);
     else
