@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcineflow_hip.so")
+LIB_PATH = os.environ.get("CINEFLOW_LIB") or os.path.join(_HERE, "libcineflow_hip.so")   # CINEFLOW_LIB: A/B builds of the same ABI
 
 
 class CineflowLibraryError(RuntimeError):
