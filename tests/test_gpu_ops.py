@@ -103,6 +103,32 @@ def test_warp_labels(dev, golden):
         assert abs(OO.dice(out.numpy(), ref.numpy(), k) - 1.0) <= 1e-3
 
 
+def test_warp_family_four_pixel_kernels_full_size(dev):
+    """The W % 4 == 0 kernels (four pixels per thread, taps through a buffer resource) at 256x256 and at a width that is not a multiple of
+    four (one-pixel kernels): the Jacobian is bit-identical to numpy (every product and sum rounds on its own: warp.hip is built with
+    -ffp-contract=off), the label warp agrees with the oracle on every pixel of a random label map, the image warp is within 2 ulp of ATen."""
+    from cineflow import ops
+    from oracle import ops as OO
+    for (B, C, H, W, amp) in [(3, 2, 256, 256, 3.0), (2, 1, 40, 24, 5.0), (2, 2, 33, 47, 8.0)]:
+        flow, src = amp * randn(B, 2, H, W, seed=H), randn(B, C, H, W, seed=W)
+        out = ops.warp_bilinear(flow.to(dev), src.to(dev)).cpu()
+        check(out, OO.warp_bilinear(flow.clone(), src), 1e-6, "warp %dx%d" % (H, W))
+        det = ops.jacobian_det(flow.to(dev)).cpu().numpy()
+        ref = np.stack([OO.jacobian_determinant(flow[b].permute(1, 2, 0).numpy().astype(np.float64)) for b in range(B)])
+        assert det.dtype == np.float64 and np.array_equal(det, ref), "jacobian %dx%d: max|diff| %.3e" % (H, W, np.abs(det - ref).max())
+        lab = (torch.rand(B, H, W, generator=torch.Generator().manual_seed(3)) * 4).to(torch.uint8)
+        wl = ops.warp_labels(flow[None].to(dev), lab.to(dev)).cpu()
+        wr = OO.warp_labels(flow[None], lab[:, None].float())[:, :, 0]
+        assert int((wl.long() != wr).sum()) == 0, "label warp %dx%d" % (H, W)
+    # taps outside the image on every side (zeros), through the out-of-range buffer offsets
+    flow = torch.zeros(1, 2, 16, 32)
+    flow[0, 0, :4], flow[0, 0, -4:], flow[0, 1, :, :8], flow[0, 1, :, -8:] = -9.5, 9.5, -11.25, 40.75
+    src = randn(1, 3, 16, 32, seed=77)
+    check(ops.warp_bilinear(flow.to(dev), src.to(dev)), OO.warp_bilinear(flow.clone(), src), 1e-6, "borders")
+    lab = (torch.rand(1, 16, 32, generator=torch.Generator().manual_seed(4)) * 4).to(torch.uint8)
+    assert torch.equal(ops.warp_labels(flow[None].to(dev), lab.to(dev)).cpu().long(), OO.warp_labels(flow[None], lab[:, None].float())[:, :, 0])
+
+
 def test_warp_3d_properties(dev):
     """3-D branch at a realistic volume size: zero flow is the identity, a pure integer shift moves the volume and zero-fills,
     and the oracle agrees on a random field."""
