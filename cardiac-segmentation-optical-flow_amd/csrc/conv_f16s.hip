@@ -73,6 +73,11 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 // the vector-memory return path (64 B/clk/CU) is what the MFMAs wait for.  With WL the workgroup fetches each fragment ONCE by LDS-DMA
 // (global_load_lds_dwordx4, no VGPRs) into a two-slot ring of tap groups (3x3: one kernel row = 3 taps per slot) and every wave reads
 // its A operands with ds_read_b128 (256 B/clk/CU); one barrier per group, the DMA of group q + 1 is in flight while group q is consumed.
+#ifdef CF_F16S_ABLATION_BUILD
+// per-phase clock sums over all waves (lane 0 of each): prologue, MFMA steps, write_stage, barrier wait, epilogue, waves
+__device__ unsigned long long g_f16s_phase[6];
+#define F16S_CLK() __builtin_readcyclecounter()
+#endif
 template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE, int WL>
 __global__ void __launch_bounds__(64 * NW + 64 * NLW, NLW ? 5 : (NW == 8 ? 4 : ((NTW <= 2 && MAXT <= 3) ? 4 : 2)))
 conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restrict__ wpk) {
@@ -87,6 +92,10 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform by construction: keep it in an SGPR
+#ifdef CF_F16S_ABLATION_BUILD
+    const unsigned long long ph_t0 = F16S_CLK();
+    unsigned long long ph_t1 = 0, ph_stage = 0, ph_bar = 0, ph_t2 = 0;
+#endif
     const int half = lane >> 5, l31 = lane & 31;
     const bool loader = NLW > 0 && wave >= NW;     // wave-uniform
     const int cw = wave % NW;                       // index among the MFMA waves
@@ -452,6 +461,9 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     if (VEC) write_stage_v(0, stgv);
     else if (NLW == 0) write_stage(0, stg0);
     __syncthreads();
+#ifdef CF_F16S_ABLATION_BUILD
+    ph_t1 = F16S_CLK();
+#endif
 
     for (int c = 0; c < g.nchunk; ++c) {
         const bool more = c + 1 < g.nchunk;
@@ -489,12 +501,25 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nt], 0, 0, 0);
             }
         }
+#ifdef CF_F16S_ABLATION_BUILD
+        const unsigned long long ph_a = F16S_CLK();
+#endif
         if (NLW == 0 && more) {
             if (VEC) write_stage_v(c + 1, stgv);
             else write_stage(c + 1, stg0);
         }
+#ifdef CF_F16S_ABLATION_BUILD
+        const unsigned long long ph_b = F16S_CLK();
+#endif
         __syncthreads();
+#ifdef CF_F16S_ABLATION_BUILD
+        ph_stage += ph_b - ph_a;
+        ph_bar += F16S_CLK() - ph_b;
+#endif
     }
+#ifdef CF_F16S_ABLATION_BUILD
+    ph_t2 = F16S_CLK();
+#endif
 
     }
 
@@ -671,6 +696,17 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
             }
         }
     }
+#ifdef CF_F16S_ABLATION_BUILD
+    if (lane == 0 && ph_t1 && (blockIdx.x & 63) == 5) {   // a sample of the workgroups: same-address atomics from every wave would dominate the run
+        const unsigned long long t3 = F16S_CLK();
+        atomicAdd(&g_f16s_phase[0], ph_t1 - ph_t0);
+        atomicAdd(&g_f16s_phase[1], (ph_t2 - ph_t1) - ph_stage - ph_bar);
+        atomicAdd(&g_f16s_phase[2], ph_stage);
+        atomicAdd(&g_f16s_phase[3], ph_bar);
+        atomicAdd(&g_f16s_phase[4], t3 - ph_t2);
+        atomicAdd(&g_f16s_phase[5], 1ULL);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -753,8 +789,12 @@ static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, h
         set_error("conv_f16s: staging tasks exceed MAXT");
         return CF_ERR_ARG;
     }
-    const size_t lds_bytes = (size_t)2 * g.NIMG * g.PH * g.PWR * REC + (PRE ? (size_t)3 * g.nchunk * CK * sizeof(float) : 0) +
+    size_t lds_bytes = (size_t)2 * g.NIMG * g.PH * g.PWR * REC + (PRE ? (size_t)3 * g.nchunk * CK * sizeof(float) : 0) +
                              (WL ? (size_t)2 * WM * WGRP * 2 * 1024 : 0);
+#ifdef CF_F16S_ABLATION_BUILD
+    { static long pad = -1; if (pad < 0) { const char* e = getenv("CF_F16S_LDSPAD"); pad = e ? atol(e) : 0; }   // timing builds: fewer resident workgroups
+      if (pad > (long)lds_bytes) lds_bytes = (size_t)pad; }
+#endif
     if (lds_bytes > 160 * 1024) {
         set_error("conv_f16s: LDS tile too large");
         return CF_ERR_ARG;
@@ -1106,3 +1146,14 @@ extern "C" int cf_conv_transpose2d_k2s2_f16s(const float* x, const void* wpk, co
     CF_REQUIRE(conv_f16s_supported(p), "unsupported configuration for the f16-split kernel (one sample of the input must stay below 2 GiB)");
     return launch_conv_f16s(p, reinterpret_cast<const _Float16*>(wpk), as_stream(stream));
 }
+
+#ifdef CF_F16S_ABLATION_BUILD
+// timing builds only: read and reset the per-phase clock sums
+extern "C" int cf_debug_f16s_phases(unsigned long long* out6) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out6, HIP_SYMBOL(cf::g_f16s_phase), 6 * sizeof(unsigned long long));
+    unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
+    hipMemcpyToSymbol(HIP_SYMBOL(cf::g_f16s_phase), z, sizeof(z));
+    return 0;
+}
+#endif
