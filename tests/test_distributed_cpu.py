@@ -82,3 +82,24 @@ def test_bench_self_launch_propagates_rank_failure():
     r = _run_bench("--gpus", "2", "--steps", "1", "--no-raft")
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_bench_warp_variant_inputs_and_dry_run():
+    """BASELINE config 1 variant: the synthetic frame pairs are deterministic per seed (ranks seed by rank, so shards differ), labels hold
+    the four classes, the displacement is a few pixels and smooth; the launcher path runs for this variant too."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    f0, i0, l0 = bench.synthetic_pairs(3, 64, 11)
+    f1, i1, l1 = bench.synthetic_pairs(3, 64, 11)
+    f2, _, _ = bench.synthetic_pairs(3, 64, 12)
+    assert torch.equal(f0, f1) and torch.equal(i0, i1) and torch.equal(l0, l1) and not torch.equal(f0, f2)
+    assert f0.shape == (3, 2, 64, 64) and i0.shape == (3, 1, 64, 64) and l0.shape == (3, 64, 64) and l0.dtype == torch.uint8
+    assert sorted(l0.unique().tolist()) == [0, 1, 2, 3] and 0.5 < float(f0.abs().max()) < 20.0
+    assert float((f0[:, :, 1:] - f0[:, :, :-1]).abs().max()) < 5.0          # smooth: a 16x16 field stretched to 64x64 (four times gentler at 256)
+    r = _run_bench("--gpus", "2", "--dry-run", "--variant", "warp", "--steps", "1", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert d["config"]["variant"] == "warp" and d["ranks_reporting"] == 2
