@@ -40,6 +40,9 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, fp32 in / fp32 accumulate
 MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA (never the 2:1-sparsity figure)
+# what a register-operand loop of v_mfma_f32_32x32x16_f16 sustains on this pool's MI355X with non-zero operands (the clock drops from
+# 2.37 to 1.64 GHz; all-zero operands reach 2482): tools/ubench/mfma_rate.hip, profiles/r02_mfma_rate.txt.  Reported beside `peak`, never instead.
+MFMA_F16_SUSTAINED_TFLOPS = 1720.0
 
 
 def synthetic_cine(B, T, S, seed):
@@ -251,6 +254,7 @@ def conv_roofline(h, dt):
         return {"bound": "mfma", "kernel": "conv_f16s_kernel (f16 MFMA, 3-term hi/lo split, fp32 accumulate)", "achieved": round(ach, 3),
                 "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4),
                 "mfma_issue_frac": round(3 * ach / MFMA_F16_PEAK_TFLOPS, 4), "vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 3),
+                "sustained_mfma_peak_measured": MFMA_F16_SUSTAINED_TFLOPS, "mfma_issue_frac_of_sustained": round(3 * ach / MFMA_F16_SUSTAINED_TFLOPS, 4),
                 "traffic": None, "traffic_note": "PMC passes are separate runs: profiles/r0*_pmc_hbm_traffic.md (1.00x algorithmic)",
                 "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "share_of_step_time": round(ms * 1e-3 / dt, 3)}
     return {"bound": "mfma", "kernel": "conv_igemm_f32_kernel<%d,2>" % (1, 2, 4)[dom], "achieved": round(ach, 3),
