@@ -425,7 +425,7 @@ def main():
     ap.add_argument("--no-raft", action="store_true", help="skip the nested BASELINE config 3 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", default="f16s", choices=["f16s", "f32"], help="f16s: f16-MFMA hi/lo split (default); f32: exact fp32 MFMA")
-    ap.add_argument("--cpu-frames", type=int, default=5)
+    ap.add_argument("--cpu-frames", type=int, default=30, help="frames of the one-slice CPU baseline sample (30 = one whole cine slice, ~15 s on 16 cores)")
     ap.add_argument("--dry-run", action="store_true", help="exercise the multi-rank path on gloo / CPU tensors without GPU work")
     args = ap.parse_args()
     if args.pairs is None:
