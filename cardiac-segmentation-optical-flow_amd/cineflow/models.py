@@ -418,6 +418,9 @@ class StackedConvLayers(Module):
                     and ops.prenorm_ok(y, nxt.cout)):
                 pending = (y, ws_b, b.instnorm)
                 continue
+            if last and nxt is not None and ws_b is not None and nxt.ks == (1, 1) and nxt.stride == 1 and ops.norm_head_ok(y, nxt.cout):
+                pending = (y, ws_b, b.instnorm)      # a 1x1 head takes the norm + LeakyReLU itself (ops.norm_head_1x1)
+                continue
             pending = None
             x = b.instnorm(y, act="lrelu", ws=ws_b)
         return (x, pending) if defer_last is not None else x
@@ -481,12 +484,22 @@ class Generic_UNet(Module):
         bott = self.conv_blocks_context[-1]
         x, pend = bott[0](x, defer_last=bott[1].first_conv())
         x = bott[1](x, pending=pend)
+        head = self.seg_outputs[-1]
         for u in range(len(self.tu)):
             up = self.tu[u](x)
             blk = self.conv_blocks_localization[u]
             x, pend = blk[0](up, x2=skips[-(u + 1)], defer_last=blk[1].first_conv())
-            x = blk[1](x, pending=pend)
-        return self.seg_outputs[-1](x)
+            if u == len(self.tu) - 1:
+                # the last stack hands its norm to the 1x1 head: one pass over the raw map instead of apply + 1x1 convolution
+                x, pend = blk[1](x, pending=pend, defer_last=head)
+                if pend is not None:
+                    raw, ws, norm = pend
+                    B, C, H, W = raw.shape
+                    coef = ops.group_norm_coef(ws, norm._p["weight"], norm._p["bias"], norm.groups, B, C, H * W, norm.eps)
+                    return ops.norm_head_1x1(raw, coef, 0.01, head._p["weight"], head._p.get("bias"))
+            else:
+                x = blk[1](x, pending=pend)
+        return head(x)
 
 
 # ------------------------------------------------------------------------------------------------ Generic_UNet (3D)

@@ -297,6 +297,22 @@ def group_norm_coef(ws, gamma, beta, groups, B, C, HW, eps=1e-5):
     return coef
 
 
+def norm_head_ok(x, K):
+    """can cf_norm_head_1x1 take the raw map x [B,C,H,W] into K classes?"""
+    return x.dim() == 4 and K in (2, 4, 8) and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[1] <= 1024 and x.is_contiguous()
+
+
+def norm_head_1x1(x, coef, slope, w, bias=None):
+    """out[b,k] = bias[k] + sum_c w[k,c] * lrelu((x[b,c] - mean) * scale + shift, slope): the deferred InstanceNorm + LeakyReLU of a raw
+    convolution output x [B,C,H,W] (coef from group_norm_coef) folded into a 1x1 head w [K,C] (Generic_UNet's seg_outputs[-1])."""
+    B, C, H, W = x.shape
+    K = w.shape[0]
+    w2 = w.reshape(K, C).contiguous()
+    out = torch.empty((B, K, H, W), dtype=torch.float32, device=x.device)
+    check(lib().cf_norm_head_1x1(_f32(x), _f32(coef), float(slope), _f32(w2), _opt(bias), _f32(out), B, C, H * W, K, _stream()), "cf_norm_head_1x1")
+    return out
+
+
 def conv2d_f16s_prenorm(x, coef, slope, wpk, wscale, bias, cout, stats_groups=None):
     """3x3 / stride 1 convolution of lrelu((x - mean) * scale + shift, slope): x is the producer's raw output, coef its
     group_norm_coef.  Returns (out, ws) with stats_groups like conv2d_f16s."""

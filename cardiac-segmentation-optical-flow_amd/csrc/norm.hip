@@ -355,6 +355,68 @@ extern "C" int cf_group_norm_coef(const double* ws, const float* gamma, const fl
     return CF_OK;
 }
 
+// Deferred normalisation into a 1x1 head (Generic_UNet's seg_outputs[-1] behind the last decoder stack, generic_UNet.py:405-408):
+//   out[b, k, p] = bias[k] + sum_c w[k, c] * lrelu((x[b, c, p] - mean[b, c]) * scale[b, c] + shift[b, c], slope)
+// x is the last convolution's raw output.  One read of x (4 C bytes per pixel) and one write of the K planes instead of the apply pass
+// (read + write 4 C) followed by a 1x1 convolution (read 4 C): the op is HBM-bound, the K * C FMAs per pixel run in fp32 in channel order.
+// Four consecutive pixels per thread (16-byte loads / stores); a block stays inside one sample so the coefficients are block-uniform and
+// sit in LDS together with the weights.
+template <int K>
+__global__ void __launch_bounds__(256) norm_head_1x1_kernel(const float* __restrict__ x, const float* __restrict__ coef, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int C, int HW, float slope,
+                                                           int blocks_per_sample) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    extern __shared__ float sm[];            // [3 C] coefficients of this sample, then [K C] weights
+    const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x - b * blocks_per_sample;
+    for (int i = threadIdx.x; i < 3 * C; i += 256) sm[i] = coef[(long)b * 3 * C + i];
+    for (int i = threadIdx.x; i < K * C; i += 256) sm[3 * C + i] = w[i];
+    __syncthreads();
+    const int p = (blk * 256 + threadIdx.x) * 4;
+    if (p >= HW) return;
+    const float* xb = x + (long)b * C * HW + p;
+    f32x4 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const float bv = bias ? bias[k] : 0.f; acc[k] = f32x4{bv, bv, bv, bv}; }
+    for (int c = 0; c < C; ++c) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)c * HW);
+        const float m = sm[c], sc = sm[C + c], sh = sm[2 * C + c];
+        f32x4 t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float u = (v[j] - m) * sc + sh;
+            t[j] = u > 0.f ? u : u * slope;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float wk = sm[3 * C + k * C + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[k][j] = fmaf(wk, t[j], acc[k][j]);
+        }
+    }
+    float* ob = out + (long)b * K * HW + p;
+#pragma unroll
+    for (int k = 0; k < K; ++k) *reinterpret_cast<f32x4*>(ob + (long)k * HW) = acc[k];
+}
+
+extern "C" int cf_norm_head_1x1(const float* x, const float* coef, float slope, const float* w, const float* bias, float* out, int B, int C,
+                                int HW, int K, void* stream) {
+    CF_REQUIRE(x && coef && w && out, "null pointer");
+    CF_REQUIRE(B > 0 && C > 0 && C <= 1024 && HW > 0 && (HW & 3) == 0 && (K == 2 || K == 4 || K == 8), "bad shape B=%d C=%d HW=%d K=%d (K in {2,4,8}, HW %% 4 == 0)",
+               B, C, HW, K);
+    CF_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, "x and out must be 16-byte aligned");
+    CF_REQUIRE(slope >= 0.f, "LeakyReLU slope must be >= 0");
+    const int bps = (HW / 4 + 255) / 256;
+    const long nblk = (long)B * bps;
+    CF_REQUIRE(nblk < (1L << 31), "grid too large");
+    const size_t lds = (size_t)(3 + K) * C * sizeof(float);
+    hipStream_t s = as_stream(stream);
+    if (K == 2) hipLaunchKernelGGL(norm_head_1x1_kernel<2>, dim3((unsigned)nblk), dim3(256), lds, s, x, coef, w, bias, out, C, HW, slope, bps);
+    else if (K == 4) hipLaunchKernelGGL(norm_head_1x1_kernel<4>, dim3((unsigned)nblk), dim3(256), lds, s, x, coef, w, bias, out, C, HW, slope, bps);
+    else hipLaunchKernelGGL(norm_head_1x1_kernel<8>, dim3((unsigned)nblk), dim3(256), lds, s, x, coef, w, bias, out, C, HW, slope, bps);
+    CF_CHECK_LAUNCH();
+    return CF_OK;
+}
+
 // cf_group_norm_apply with a residual that still awaits its own GroupNorm (same group count and eps): res_ws holds the residual's
 // (sum, sum of squares) pairs, res_gamma / res_beta its affine parameters.
 extern "C" int cf_group_norm_apply_res_norm(const float* x, const float* gamma, const float* beta, const float* res, float* out, int B, int C,

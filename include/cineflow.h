@@ -167,6 +167,12 @@ int cf_group_norm_apply_res_norm(const float* x, const float* gamma, const float
  * cf_conv2d_f16s_prenorm_ok(B, C, H, W, Cout) returns 1 when a shape qualifies (no launch), and the call fails otherwise. */
 int cf_group_norm_coef(const double* ws, const float* gamma, const float* beta, int B, int C, int HW, int groups, float eps, float* coef,
                        void* stream);
+/* Deferred normalisation into a 1x1 head: out[b][k][p] = bias[k] + sum_c w[k][c] * lrelu((x[b][c][p] - mean) * scale + shift, slope) with
+ * coef from cf_group_norm_coef -- Generic_UNet's seg_outputs[-1] (a bias-free 1x1 convolution, generic_UNet.py:405-408) behind the last
+ * decoder convolution's InstanceNorm + LeakyReLU, in one pass over that convolution's raw output.  K in {2, 4, 8}, HW % 4 == 0, fp32 FMAs
+ * in channel order; w is the [K][C] weight, bias may be NULL. */
+int cf_norm_head_1x1(const float* x, const float* coef, float slope, const float* w, const float* bias, float* out, int B, int C, int HW,
+                     int K, void* stream);
 int cf_conv2d_f16s_prenorm_ok(int B, int C, int H, int W, int Cout);
 int cf_conv2d_f16s_prenorm(const float* x, int C, const float* in_norm, float in_slope, const void* wpk, const float* bias, float* out,
                            int B, int H, int W, int Cout, float alpha, double* gn_ws, int gn_groups, void* stream);

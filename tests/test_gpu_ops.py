@@ -796,3 +796,27 @@ def test_export_resampling(dev, shape, new, order, sep, axis, oz):
     assert ops.resample_data_or_seg(data, shape, False, axis, order, sep, oz) is data
     const = np.full((1,) + tuple(shape), 2.5, np.float32)
     check(torch.from_numpy(ops.resample_data_or_seg(const, new, False, axis, order, sep, oz)), np.full((1,) + tuple(new), 2.5), 1e-6)
+
+def test_norm_head_1x1_vs_separate_passes(dev):
+    """cf_norm_head_1x1 (deferred InstanceNorm + LeakyReLU folded into Generic_UNet's 1x1 head, generic_UNet.py:405-408) against the
+    oracle's two steps -- F.instance_norm(affine) + leaky_relu, then a bias-free 1x1 convolution -- and against the device's own
+    apply-pass + 1x1 route; 32 channels x 4 classes at 256x256 (the bench U-Net's head) and an odd shape."""
+    from cineflow import ops
+    for (B, C, H, W, K, with_bias) in [(3, 32, 256, 256, 4, False), (2, 20, 12, 36, 2, True), (1, 64, 64, 64, 8, False)]:
+        raw = (2.0 * randn(B, C, H, W, seed=C) + randn(1, C, 1, 1, seed=K)).to(dev)
+        gamma, beta = (1.0 + 0.2 * randn(C, seed=1)).to(dev), (0.1 * randn(C, seed=2)).to(dev)
+        w = (randn(K, C, 1, 1, seed=3) / math.sqrt(C)).to(dev)
+        bias = (0.3 * randn(K, seed=4)).to(dev) if with_bias else None
+        ref = F.conv2d(F.leaky_relu(F.instance_norm(raw.cpu().double(), weight=gamma.cpu().double(), bias=beta.cpu().double(), eps=1e-5), 0.01),
+                       w.cpu().double(), None if bias is None else bias.cpu().double())
+        # statistics exactly as the producing convolution would leave them: fp64 {sum, sum of squares} per (sample, channel)
+        ws = torch.stack([raw.double().sum((2, 3)), (raw.double() ** 2).sum((2, 3))], dim=2).reshape(-1).contiguous()
+        coef = ops.group_norm_coef(ws, gamma, beta, C, B, C, H * W, 1e-5)
+        assert ops.norm_head_ok(raw, K)
+        out = ops.norm_head_1x1(raw, coef, 0.01, w, bias)
+        assert out.shape == (B, K, H, W)
+        check(out, ref, 2e-5, "norm_head %dx%dx%d" % (C, H, W))
+        applied = ops.group_norm_apply(raw, gamma, beta, C, ws, eps=1e-5, act="lrelu")
+        two_pass = F.conv2d(applied.cpu().double(), w.cpu().double(), None if bias is None else bias.cpu().double())
+        check(out, two_pass, 2e-5, "norm_head vs apply + 1x1")
+    assert not ops.norm_head_ok(torch.zeros(1, 4, 3, 3, device=dev), 4) and not ops.norm_head_ok(torch.zeros(1, 4, 4, 4, device=dev), 3)
