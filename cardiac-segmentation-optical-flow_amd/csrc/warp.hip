@@ -229,7 +229,10 @@ __global__ void __launch_bounds__(256) jacobian_det_2d_v4_kernel(const float* __
                                                                  int W) {
     const unsigned HW = (unsigned)(H * W);
     const unsigned nq = (unsigned)B * HW / 4;
-    for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+    // XCD-banded block order (grid is a multiple of 8): neighbouring blocks, which read each other's border rows, run on ONE XCD and meet
+    // in its L2 -- round-robin they fetched every border row once per XCD (PMC FETCH_SIZE 1.59x the algorithmic read before this)
+    const unsigned bid = (gridDim.x & 7) ? blockIdx.x : (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    for (unsigned q = bid * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
         const unsigned e = q * 4;
         const unsigned b = e / HW;
         const unsigned p = e - b * HW;

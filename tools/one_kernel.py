@@ -54,6 +54,23 @@ elif kind == "lookup":       # python tools/one_kernel.py lookup B
     coords = ops.coords_grid(B, 32, 32, dev) + 3 * torch.randn(B, 2, 32, 32, generator=g).to(dev)
     for _ in range(5):
         ops.corr_lookup(pyr, coords, 4, 4)
+elif kind == "warp":         # python tools/one_kernel.py warp B   (BASELINE config 1: warp + label warp + Jacobian of B 256x256 pairs)
+    sys.path.insert(0, ROOT)
+    import bench
+    B = int(sys.argv[2])
+    flow, img, lab = (t.to(dev) for t in bench.synthetic_pairs(B, 256, 7))
+    for _ in range(3):
+        ops.warp_bilinear(flow, img)
+        ops.warp_labels(flow[None], lab)
+        ops.jacobian_det(flow)
+elif kind == "head":         # python tools/one_kernel.py head B   (norm + LeakyReLU + 1x1 head, 32 channels -> 4 classes at 256x256)
+    B = int(sys.argv[2])
+    raw = torch.randn(B, 32, 256, 256, generator=g).to(dev)
+    ws = torch.stack([raw.double().sum((2, 3)), (raw.double() ** 2).sum((2, 3))], dim=2).reshape(-1).contiguous()
+    coef = ops.group_norm_coef(ws, None, None, 32, B, 32, 65536)
+    w = torch.randn(4, 32, 1, 1, generator=g).to(dev)
+    for _ in range(3):
+        ops.norm_head_1x1(raw, coef, 0.01, w)
 elif kind == "sep":          # python tools/one_kernel.py sep 1x5|5x1 B   (SepConvGRU gates 128+256 -> 256 at 32x32)
     kh, kw = (1, 5) if sys.argv[2] == "1x5" else (5, 1)
     B = int(sys.argv[3])
