@@ -75,7 +75,7 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 // its A operands with ds_read_b128 (256 B/clk/CU); one barrier per group, the DMA of group q + 1 is in flight while group q is consumed.
 #ifdef CF_F16S_ABLATION_BUILD
 // per-phase clock sums over all waves (lane 0 of each): prologue, MFMA steps, write_stage, barrier wait, epilogue, waves
-__device__ unsigned long long g_f16s_phase[6];
+__device__ unsigned long long g_f16s_phase[9];   // [6..8]: epilogue split: scale + activation, coordinates + stores, statistics
 #define F16S_CLK() __builtin_readcyclecounter()
 #endif
 template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE, int WL>
@@ -613,6 +613,9 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
             r_off[nt] = (long)b * p.Cout * HoWo + (long)oy * p.Wo + ox;
         }
     };
+#ifdef CF_F16S_ABLATION_BUILD
+    const unsigned long long ph_e1 = F16S_CLK();
+#endif
     {
     out_coords();
 #pragma unroll
@@ -637,6 +640,9 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
         }
     }
     }
+#ifdef CF_F16S_ABLATION_BUILD
+    const unsigned long long ph_e2 = F16S_CLK();
+#endif
     if (do_stats) {
         auto xreduce = [&](float (&v)[16]) {
             // after this, lane bits (b4 b3 b2 b1) select register 8*b4 + 4*b3 + 2*b2 + b1, summed over the 32 lanes of the half
@@ -705,6 +711,9 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
         atomicAdd(&g_f16s_phase[3], ph_bar);
         atomicAdd(&g_f16s_phase[4], t3 - ph_t2);
         atomicAdd(&g_f16s_phase[5], 1ULL);
+        atomicAdd(&g_f16s_phase[6], ph_e1 - ph_t2);
+        atomicAdd(&g_f16s_phase[7], ph_e2 - ph_e1);
+        atomicAdd(&g_f16s_phase[8], t3 - ph_e2);
     }
 #endif
 }
@@ -1149,10 +1158,10 @@ extern "C" int cf_conv_transpose2d_k2s2_f16s(const float* x, const void* wpk, co
 
 #ifdef CF_F16S_ABLATION_BUILD
 // timing builds only: read and reset the per-phase clock sums
-extern "C" int cf_debug_f16s_phases(unsigned long long* out6) {
+extern "C" int cf_debug_f16s_phases(unsigned long long* out9) {
     hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out6, HIP_SYMBOL(cf::g_f16s_phase), 6 * sizeof(unsigned long long));
-    unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
+    hipMemcpyFromSymbol(out9, HIP_SYMBOL(cf::g_f16s_phase), 9 * sizeof(unsigned long long));
+    unsigned long long z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipMemcpyToSymbol(HIP_SYMBOL(cf::g_f16s_phase), z, sizeof(z));
     return 0;
 }

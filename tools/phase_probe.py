@@ -19,10 +19,10 @@ for (C1, C2, H, Cout, k, stride) in cases:
     pad = (k // 2, k // 2)
     Ho = (H + 2 * pad[0] - k) // stride + 1
     out = torch.empty(B, Cout, Ho, Ho, device=dev)
-    run = lambda: ops.conv2d_f16s(x1, wpk, ws, None, Cout, k, k, stride, pad, x2=x2, out=out)
+    run = lambda: ops.conv2d_f16s(x1, wpk, ws, None, Cout, k, k, stride, pad, x2=x2, out=out, stats_groups=8)
     for _ in range(3):
         run()
-    buf = (ctypes.c_ulonglong * 6)()
+    buf = (ctypes.c_ulonglong * 9)()
     h.cf_debug_f16s_phases(buf)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 5
@@ -41,3 +41,4 @@ for (C1, C2, H, Cout, k, stride) in cases:
     print("C%d+%d %dx%d -> %d k%d s%d: %.1f us %.1f TF | waves/launch %d | per wave clk: %s | total %.0f" % (
         C1, C2, H, H, Cout, k, stride, us, flops / us / 1e6, waves // n,
         "  ".join("%s %.0f (%.0f%%)" % (nm, v[i] / waves, 100.0 * v[i] / tot) for i, nm in enumerate(names)), tot / waves), flush=True)
+    print("      epilogue split: scale+act %.0f  coords+stores %.0f  statistics %.0f" % (v[6] / waves, v[7] / waves, v[8] / waves), flush=True)
