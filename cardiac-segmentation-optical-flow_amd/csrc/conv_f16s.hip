@@ -591,9 +591,20 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
             break;
         default: break;
     }
-    // output coordinates are derived here rather than ahead of the main loop: 4*NTW fewer registers live across it
+    // output coordinates are derived here rather than ahead of the main loop: 4*NTW fewer registers live across it.
+    // Stores go through a buffer resource over the NIMG output samples of this workgroup: one 32-bit add per store, and a pixel outside the
+    // tile / a channel beyond Cout is an out-of-range offset (the store is dropped by the range check) instead of a branch around the store
+    // and a 64-bit address per element.  Two parking values so that "both invalid" cannot wrap back into range; the host keeps
+    // NIMG x (output sample bytes) below 1 GiB (launch_f16s_v).
+    constexpr unsigned OOB_PX = 0x80000000u, OOB_CH = 0x40000000u;
+    const unsigned up4 = p.scatter2x2 ? 4u : 1u;
+    const unsigned osample = (unsigned)p.out_ctotal * (unsigned)HoWo * up4;                    // elements per output sample
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        p.out + ((long)b0 * p.out_ctotal + p.out_coff) * (long)HoWo * up4, 0,
+        (int)(((unsigned)(b0 + g.NIMG <= p.B ? g.NIMG : p.B - b0) * osample - (unsigned)p.out_coff * (unsigned)HoWo * up4) * 4u), 0x00020000);
     bool o_ok[NTW];
-    long o_off[NTW], r_off[NTW];
+    unsigned o_off[NTW];
+    long r_off[NTW];
     auto out_coords = [&]() {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
@@ -606,10 +617,8 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
             if (!in_tile) { img = 0; tyy = 0; txx = 0; }
             int b = b0 + img, oy = y0 + tyy, ox = x0 + txx;
             o_ok[nt] = in_tile && b < p.B && oy < p.Ho && ox < p.Wo;
-            if (p.scatter2x2)
-                o_off[nt] = ((long)b * p.out_ctotal + p.out_coff) * (4L * HoWo) + (long)(2 * oy) * (2 * p.Wo) + 2 * ox;
-            else
-                o_off[nt] = ((long)b * p.out_ctotal + p.out_coff) * (long)HoWo + (long)oy * p.Wo + ox;
+            const unsigned px = p.scatter2x2 ? (unsigned)(2 * oy) * (unsigned)(2 * p.Wo) + 2u * ox : (unsigned)oy * p.Wo + ox;
+            o_off[nt] = o_ok[nt] ? ((unsigned)img * osample + px) * 4u : OOB_PX;
             r_off[nt] = (long)b * p.Cout * HoWo + (long)oy * p.Wo + ox;
         }
     };
@@ -621,22 +630,24 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (co >= p.Cout) continue;
-        long ochan;
+        const bool co_ok = co < p.Cout;
+        unsigned ochan;
         if (p.scatter2x2) {
-            const int cr = co >> 2, dy = (co >> 1) & 1, dx = co & 1;
-            ochan = (long)cr * (4L * HoWo) + (long)dy * (2 * p.Wo) + dx;
+            const unsigned cr = (unsigned)co >> 2, dy = ((unsigned)co >> 1) & 1u, dx = (unsigned)co & 1u;
+            ochan = (cr * (4u * HoWo) + dy * (2u * p.Wo) + dx) * 4u;
         } else {
-            ochan = (long)co * HoWo;
+            ochan = (unsigned)co * (unsigned)HoWo * 4u;
         }
+        if (!co_ok) ochan = OOB_CH;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            if (!o_ok[nt]) continue;
+            const bool ok = o_ok[nt] && co_ok;
             float v = acc1[nt][r];
-            if (p.res) v += p.res[r_off[nt] + (long)co * HoWo];   // rare (SingleConv / Linear residuals)
-            p.out[o_off[nt] + ochan] = v;
-            ssum[r] += v;
-            ssq[r] += v * v;
+            if (p.res) { if (ok) v += p.res[r_off[nt] + (long)co * HoWo]; }   // rare (SingleConv / Linear residuals)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, o_off[nt] + ochan, 0, 0);
+            const float m = ok ? v : 0.f;
+            ssum[r] += m;
+            ssq[r] += m * m;
         }
     }
     }
@@ -804,6 +815,10 @@ static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, h
     { static long pad = -1; if (pad < 0) { const char* e = getenv("CF_F16S_LDSPAD"); pad = e ? atol(e) : 0; }   // timing builds: fewer resident workgroups
       if (pad > (long)lds_bytes) lds_bytes = (size_t)pad; }
 #endif
+    if ((double)g.NIMG * p.out_ctotal * p.Ho * p.Wo * (p.scatter2x2 ? 4.0 : 1.0) * 4.0 >= 1073741824.0) {
+        set_error("conv_f16s: one workgroup's output samples must stay below 1 GiB (32-bit store offsets)");
+        return CF_ERR_ARG;
+    }
     if (lds_bytes > 160 * 1024) {
         set_error("conv_f16s: LDS tile too large");
         return CF_ERR_ARG;
