@@ -416,7 +416,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--slices", type=int, default=32, help="cine slices per step and per GPU (B)")
+    ap.add_argument("--slices", type=int, default=64, help="cine slices per step and per GPU (B); 32 -> 48 -> 64 measured 707.8 -> 713.0 -> 717.4 frames/s on one box")
     ap.add_argument("--frames", type=int, default=30, help="frames per cine slice (T)")
     ap.add_argument("--pairs", type=int, default=None, help="frame pairs per step and per GPU (default: 64 for raft, 960 for warp)")
     ap.add_argument("--variant", default="video", choices=["video", "raft_config", "raft", "warp"],
