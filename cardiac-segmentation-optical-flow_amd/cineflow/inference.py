@@ -293,6 +293,8 @@ def chunk_orders(T):
 # CF_TWO_STREAMS=1: segmentation U-Net and flow recurrence on two HIP streams.  Measured +2.6 % frames/s (676.7 vs 659.2 on one box); OFF by
 # default because overlapping kernels make the per-kernel event durations of bench.py's roofline (and rocprof's) meaningless.
 TWO_STREAMS = os.environ.get("CF_TWO_STREAMS", "0") == "1"
+# CF_RAGGED_CHUNKS=0: the two ED-anchored half sequences of unequal length run one after the other (A/B knob)
+RAGGED_CHUNKS = os.environ.get("CF_RAGGED_CHUNKS", "1") == "1"
 _side = {}
 
 
@@ -332,9 +334,20 @@ def predict_cine_slices(flow_net, seg_net, frames, ed_labels=None, do_mirroring=
     # TTA-averaged (:3162).  Both chunks run as one batch of 2B sequences when they have equal length.
     flow = torch.zeros((T, B, 2, H, W), dtype=torch.float32, device=dev)
     o1, o2 = chunk_orders(T)
+    ragged = len(o1) == len(o2) + 1 and len(o2) > 1 and RAGGED_CHUNKS and hasattr(flow_net, "_narrow") and not getattr(flow_net, "raft", False)
     if len(o1) == len(o2) and len(o1) > 1:
         xin = torch.cat([frames[o1], frames[o2]], dim=1)  # [Tc, 2B, 1, H, W]  (copies only)
         bf = flow_net(xin)["backward_flow"]
+        for j, t in enumerate(o1[1:]):
+            flow[t] = bf[j, :B]
+        for j, t in enumerate(o2[1:]):
+            flow[t] = bf[j, B:]
+    elif ragged:
+        # T even (T = 30: 15 + 14 frames behind ED): the common steps of both groups run as one batch of 2B sequences, the last step of the
+        # longer group alone.  Twice the work per launch for 28 of 29 steps; per-sequence numbers are those of separate calls.
+        o2p = o2 + [o2[-1]]                                 # padding frame of the shorter group: never consumed
+        xin = torch.cat([frames[o1], frames[o2p]], dim=1)   # [Tc, 2B, 1, H, W]
+        bf = flow_net(xin, keep_from=len(o2), keep=B)["backward_flow"]
         for j, t in enumerate(o1[1:]):
             flow[t] = bf[j, :B]
         for j, t in enumerate(o2[1:]):

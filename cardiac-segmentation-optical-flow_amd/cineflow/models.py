@@ -193,12 +193,34 @@ class SegFlowGaussian(Module):
         if raft:
             self.update_block = BasicUpdateBlock(hidden_dim=d_model // 2)
 
-    def forward(self, x):
+    def forward(self, x, keep_from=None, keep=None):
+        """keep_from / keep (not in the reference, whose forward runs one sequence batch): from recurrence step `keep_from` on only the first
+        `keep` sequences of the batch go on (their state is sliced out) -- lets two sequence groups of lengths T and T-1 share the launches of
+        their common steps (cineflow.inference.predict_cine_slices).  The returned flow is [T-1, B, ...]; rows >= keep of the steps >= keep_from
+        are zero.  No kernel mixes batch entries; per-sequence results differ from separate calls only through the launch shapes the batch size
+        selects (~5e-6 px measured)."""
         if self.raft:
+            assert keep_from is None, "ragged batches are built for the two recurrent dispatches only"
             return self.forward_multi_task_flow_deformable_raft(x)
         if self.motion_appearance:
-            return self.forward_motion_appearance(x)
-        return self.forward_multi_task_flow_deformable_cost_volume_transformer_cat(x)
+            return self.forward_motion_appearance(x, keep_from, keep)
+        return self.forward_multi_task_flow_deformable_cost_volume_transformer_cat(x, keep_from, keep)
+
+    @staticmethod
+    def _narrow(t, n):
+        if isinstance(t, (list, tuple)):
+            return [SegFlowGaussian._narrow(u, n) for u in t]
+        return t[:n].contiguous()
+
+    @staticmethod
+    def _stack_flows(flows, B):
+        """per-step cumulative flows (the last ones possibly for fewer sequences) -> [T-1, B, 2, H, W]"""
+        if all(f.shape[0] == B for f in flows):
+            return torch.stack(flows, dim=0)
+        out = torch.zeros((len(flows), B) + tuple(flows[0].shape[1:]), dtype=flows[0].dtype, device=flows[0].device)
+        for i, f in enumerate(flows):
+            out[i, :f.shape[0]] = f
+        return out
 
     def _step_tail(self, f1, f2, hidden, new_skips, cum, x0, xt):
         """SegFlowGaussian.py:1410-1435 == :1878-1905."""
@@ -209,9 +231,10 @@ class SegFlowGaussian(Module):
         past_motion, past_skips = self.memory_encoder(ops.memory_input(x0, xt, cum))
         return hidden, cum, past_motion, past_skips
 
-    def forward_motion_appearance(self, x):
+    def forward_motion_appearance(self, x, keep_from=None, keep=None):
         """SegFlowGaussian.py:1813-1912."""
         T, B, C, H, W = x.shape
+        B_all = B
         dev = x.device
         cum = torch.zeros((B, 2, H, W), dtype=torch.float32, device=dev)
         hidden = torch.zeros((B, self.d_model, self.H, self.W), dtype=torch.float32, device=dev)
@@ -222,22 +245,31 @@ class SegFlowGaussian(Module):
         first_app, _, _ = self.query_encoder(pair)
         prev_app = first_app
         flows = []
+        x0 = x[0]
         for t in range(1, T):
+            xt, xp = x[t], x[t - 1]
+            if keep_from is not None and t >= keep_from:
+                if B != keep:      # the shorter group is done: slice the recurrent state of the longer one out of the batch
+                    B = keep
+                    cum, hidden, past_motion, past_skips, first_app, prev_app, x0 = self._narrow(
+                        (cum, hidden, past_motion, past_skips, first_app, prev_app, x0), B)
+                xt, xp = xt[:B], xp[:B]
             pair = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
-            ops.copy_channels(x[t], 0, 1, dst=pair, dst_coff=0)
-            ops.copy_channels(x[t - 1], 0, 1, dst=pair, dst_coff=1)
+            ops.copy_channels(xt, 0, 1, dst=pair, dst_coff=0)
+            ops.copy_channels(xp, 0, 1, dst=pair, dst_coff=1)
             cur_app, _cur_motion, skips = self.query_encoder(pair)
             new_skips = [self.skip_co_reduction_list[s](skips[s], x2=past_skips[s]) for s in range(self.num_stages)]
             f1 = self.bottleneck1(query=cur_app, key=prev_app, value=prev_app)
             f2 = self.bottleneck2(query=cur_app, key=first_app, value=past_motion)
-            hidden, cum, past_motion, past_skips = self._step_tail(f1, f2, hidden, new_skips, cum, x[0], x[t])
+            hidden, cum, past_motion, past_skips = self._step_tail(f1, f2, hidden, new_skips, cum, x0, xt)
             flows.append(cum)
             prev_app = cur_app
-        return {"backward_flow": torch.stack(flows, dim=0)}
+        return {"backward_flow": self._stack_flows(flows, B_all)}
 
-    def forward_multi_task_flow_deformable_cost_volume_transformer_cat(self, x):
+    def forward_multi_task_flow_deformable_cost_volume_transformer_cat(self, x, keep_from=None, keep=None):
         """SegFlowGaussian.py:1330-1447 (skip_co_type 'both', correlation_value False, warp False)."""
         T, B, C, H, W = x.shape
+        B_all = B
         dev = x.device
         cum = torch.zeros((B, 2, H, W), dtype=torch.float32, device=dev)
         hidden = torch.zeros((B, self.d_model, self.H, self.W), dtype=torch.float32, device=dev)
@@ -245,8 +277,16 @@ class SegFlowGaussian(Module):
         first_feat, first_skips = self.query_encoder(x[0])
         prev_feat, prev_skips = first_feat, first_skips
         flows = []
+        x0 = x[0]
         for t in range(1, T):
-            cur_feat, cur_skips = self.query_encoder(x[t])
+            xt = x[t]
+            if keep_from is not None and t >= keep_from:
+                if B != keep:      # the shorter group is done: slice the recurrent state of the longer one out of the batch
+                    B = keep
+                    cum, hidden, past_motion, past_skips, first_feat, prev_feat, prev_skips, x0 = self._narrow(
+                        (cum, hidden, past_motion, past_skips, first_feat, prev_feat, prev_skips, x0), B)
+                xt = xt[:B].contiguous()
+            cur_feat, cur_skips = self.query_encoder(xt)
             new_skips = []
             for s in range(self.num_stages):
                 corr = self.cost_volume_computation_list[s](cur_skips[s], prev_skips[s])
@@ -254,10 +294,10 @@ class SegFlowGaussian(Module):
                 new_skips.append(self.skip_co_reduction_list[s](corr, x2=past_skips[s]))
             f1 = self.bottleneck1(query=cur_feat, key=prev_feat, value=prev_feat)
             f2 = self.bottleneck2(query=cur_feat, key=first_feat, value=past_motion)
-            hidden, cum, past_motion, past_skips = self._step_tail(f1, f2, hidden, new_skips, cum, x[0], x[t])
+            hidden, cum, past_motion, past_skips = self._step_tail(f1, f2, hidden, new_skips, cum, x0, xt)
             flows.append(cum)
             prev_feat, prev_skips = cur_feat, cur_skips
-        return {"backward_flow": torch.stack(flows, dim=0)}
+        return {"backward_flow": self._stack_flows(flows, B_all)}
 
     def forward_multi_task_flow_deformable_raft(self, x):
         """SegFlowGaussian.py:875-969; element [0] of the encoders' (feature, skips) tuple is used where the

@@ -303,6 +303,45 @@ def test_joint_cine_pipeline_vs_oracle(dev):
         assert np.isnan(d) or abs(d - 1.0) <= 1e-3
 
 
+@pytest.mark.parametrize("ma", [False, True])
+def test_joint_cine_pipeline_ragged_half_sequences(dev, ma):
+    """T even (the bench's T = 30): the two ED-anchored half sequences differ in length by one; their common steps run as one batch of 2B
+    sequences and the last step of the longer one alone (SegFlowGaussian.forward keep_from / keep).  Per-sequence flows must agree with the
+    one-after-the-other schedule (no kernel mixes batch entries) and stay within the oracle bar."""
+    from cineflow.models import SegFlowGaussian, Generic_UNet
+    from cineflow import inference
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    kw = dict(image_size=64, in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=32, bottleneck_heads=4, dim_feedforward=48,
+              motion_appearance=ma)
+    fnet = load(SegFlowGaussian(**kw), 21, dev)
+    snet = load(Generic_UNet(1, 8, 4, 3), 20, dev)
+    Tn, B = 6, 3
+    o1, o2 = inference.chunk_orders(Tn)
+    assert len(o1) == len(o2) + 1
+    frames = randn(Tn, B, 1, 64, 64, seed=101)
+    assert inference.RAGGED_CHUNKS
+    out = inference.predict_cine_slices(fnet, snet, frames.to(dev))
+    inference.RAGGED_CHUNKS = False
+    try:
+        seq = inference.predict_cine_slices(fnet, snet, frames.to(dev))
+    finally:
+        inference.RAGGED_CHUNKS = True
+    # not bit-identical: the batch size picks the convolution shapes (tile sizes, fp32 summation order) and the order of the statistics
+    # atomics; the schedules agree to ~5e-6 px, a twentieth of the bar
+    assert float((out["flow"] - seq["flow"]).abs().max()) <= 2e-5
+    assert float((out["registered"] == seq["registered"]).float().mean()) >= 0.9999
+    ofnet = fill_module_(OM.SegFlowGaussian(**kw), 21)
+    with torch.no_grad():
+        flow = torch.zeros(Tn, B, 2, 64, 64)
+        for order in (o1, o2):
+            bf = ofnet(frames[order])["backward_flow"]
+            for j, t in enumerate(order[1:]):
+                flow[t] = bf[j]
+    assert OO.mean_epe(out["flow"].cpu(), flow) <= 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ full size / long recurrence (VERDICT r1)
 def smooth_cine(T_, B, S_, seed):
     """z-scored synthetic cine frames of the bench (annulus + blobs + noise): realistic flows, not white noise"""
