@@ -953,11 +953,23 @@ static int launch_conv_f16s_part(const ConvParams& p, const _Float16* wpk, hipSt
 // The kernel addresses its inputs with 32-bit buffer offsets (< 2 GiB per descriptor).  A batch whose input tensors are larger is
 // cut into sub-batches HERE (same kernel, same numbers, a few more launches) instead of being handed to another kernel: the batch
 // axis is the outermost one of every operand, so a sub-batch is a pointer offset.
-int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
+// Samples per sub-batch: the batch is cut into the FEWEST parts that fit and the parts are made equal (the last one at most parts - 1
+// samples smaller) -- a greedy cut could leave a remainder of one sample, for which the dispatch picks another kernel shape than for the
+// large parts (one that e.g. lacks the deferred input normalisation although the capability probe, asked with the whole batch, said yes).
+static long f16s_sub_batch(const ConvParams& p) {
     const long HW = (long)p.H * p.W;
     const long per1 = (long)p.C1 * HW * 4, per2 = (long)p.C2 * HW * 4;
     const long lim = (1L << 31) - 1;
-    long nb = lim / (per1 > per2 ? per1 : per2);
+    const long nb = lim / (per1 > per2 ? per1 : per2);
+    if (nb < 1) return 0;
+    if (p.B <= nb) return p.B;
+    const long parts = (p.B + nb - 1) / nb;
+    return (p.B + parts - 1) / parts;
+}
+
+int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
+    const long HW = (long)p.H * p.W;
+    const long nb = f16s_sub_batch(p);
     if (nb < 1) { set_error("conv_f16s: one sample of the input exceeds 2 GiB"); return CF_ERR_ARG; }
     if (p.B <= nb) return launch_conv_f16s_part(p, wpk, s);
     const int up = p.scatter2x2 ? 2 : 1;
@@ -1139,7 +1151,17 @@ extern "C" int cf_conv2d_f16s_prenorm_ok(int B, int C, int H, int W, int Cout) {
     prenorm_params(p, dummy, C, nullptr, dummy, B, H, W, Cout, 1.f, nullptr, 0, dummy, 0.01f);
     p.probe = 1;
     if (!conv_f16s_supported(p)) return 0;
-    return launch_conv_f16s_impl(p, reinterpret_cast<const _Float16*>(dummy), nullptr, nullptr) == CF_OK ? 1 : 0;
+    // the shapes are chosen per sub-batch (launch_conv_f16s): ask for the sizes that will actually be launched
+    const long nb = f16s_sub_batch(p);
+    if (nb < 1) return 0;
+    const long last = B - (B - 1) / nb * nb;
+    p.B = (int)nb;
+    if (launch_conv_f16s_impl(p, reinterpret_cast<const _Float16*>(dummy), nullptr, nullptr) != CF_OK) return 0;
+    if (last != nb) {
+        p.B = (int)last;
+        if (launch_conv_f16s_impl(p, reinterpret_cast<const _Float16*>(dummy), nullptr, nullptr) != CF_OK) return 0;
+    }
+    return 1;
 }
 
 extern "C" int cf_conv2d_f16s_prenorm(const float* x, int C, const float* in_norm, float in_slope, const void* wpk, const float* bias, float* out,

@@ -357,12 +357,36 @@ def test_conv2d_f16s_batch_split(dev):
     wpk, ws = ops.pack_conv_weight_f16s(w)
     assert x.numel() * 4 >= 2 ** 31
     out, st = ops.conv2d_f16s(x, wpk, ws, b, Cout, 3, 3, 1, (1, 1), act="relu", stats_groups=4)
-    for i in (0, 7, 8):                                # first sub-batch, its last sample, the second sub-batch
+    for i in (0, 4, 7, 8):                             # samples of both sub-batches (9 = 5 + 4: equal parts, see the next test)
         oi, si = ops.conv2d_f16s(x[i:i + 1], wpk, ws, b, Cout, 3, 3, 1, (1, 1), act="relu", stats_groups=4)
         assert torch.equal(out[i:i + 1], oi)
         assert torch.allclose(st.view(B, 4, 2)[i], si.view(4, 2), rtol=1e-7, atol=0)    # fp32 partial sums meet in another order
     ref = F.relu(F.conv2d(x[8:9].cpu().double(), w.cpu().double(), b.cpu().double(), padding=1))
     check(out[8:9], ref, 1e-5, "batch split")
+
+
+def test_conv2d_f16s_prenorm_sub_batches_are_equal_parts(dev):
+    """512 samples of 4 MiB: a descriptor holds 511, and a greedy cut would leave ONE sample, for which the dispatch picks the 8-wave
+    shape of the small launches -- which has no deferred input normalisation although the capability probe (asked with 512) said yes.
+    The batch is cut into equal parts (2 x 256) and the probe asks for the part sizes."""
+    from cineflow import ops
+    B, C, H = 512, 256, 64
+    torch.manual_seed(5)
+    raw = torch.randn(B, C, H, H, device=dev)
+    assert ops.prenorm_ok(raw, C)
+    w = (torch.randn(C, C, 3, 3, device=dev) / math.sqrt(9 * C))
+    wpk, wsc = ops.pack_conv_weight_f16s(w)
+    ws = torch.stack([raw.double().sum((2, 3)), (raw.double() ** 2).sum((2, 3))], dim=2).view(B, 8, C // 8, 2).sum(2).reshape(-1).contiguous()
+    coef = ops.group_norm_coef(ws, None, None, 8, B, C, H * H)
+    out = ops.conv2d_f16s_prenorm(raw, coef, -1.0, wpk, wsc, None, C)
+    for lo, hi in ((0, 3), (253, 259), (509, 512)):      # across the cut at 256 and at both ends, against the two-pass route
+        sl = raw[lo:hi].contiguous()
+        assert not ops.prenorm_ok(sl, C)                  # a handful of samples: the small-launch shape, no deferred normalisation
+        applied = ops.group_norm_apply(sl, None, None, 8, ws.view(B, -1)[lo:hi].reshape(-1).contiguous(), act="gelu")
+        part = ops.conv2d_f16s(applied, wpk, wsc, None, C, 3, 3, 1, (1, 1))
+        check(out[lo:hi], part.cpu(), 1e-5, "sub-batch %d:%d" % (lo, hi))
+    ref = F.conv2d(F.gelu(F.group_norm(raw[511:512].cpu().double(), 8)), w.cpu().double(), padding=1)
+    check(out[511:512], ref, 2e-5, "last sample vs fp64 reference")
 
 
 def test_conv2d_f16s_nonfinite_inputs_propagate(dev):
