@@ -179,8 +179,10 @@ __global__ void __launch_bounds__(256) warp_bilinear_2d_v4_kernel(const float* _
     }
 }
 
+template <int KT>   // KT > 0: the class count as a compile-time constant (the class loop unrolls); 0: run-time K
 __global__ void __launch_bounds__(256) warp_labels_2d_v4_kernel(const float* __restrict__ flow, const uint8_t* __restrict__ labels,
-                                                                uint8_t* __restrict__ out, int T, int B, int K, int H, int W) {
+                                                                uint8_t* __restrict__ out, int T, int B, int Krt, int H, int W) {
+    const int K = KT ? KT : Krt;
     const unsigned HW = (unsigned)(H * W);
     const unsigned nq = (unsigned)T * B * HW / 4;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(labels), 0, (int)((unsigned)B * HW), 0x00020000);
@@ -212,6 +214,7 @@ __global__ void __launch_bounds__(256) warp_labels_2d_v4_kernel(const float* __r
         for (int k = 0; k < 4; ++k) {
             float best = -1.f;
             int arg = 0;
+#pragma unroll
             for (int c = 0; c < K; ++c) {
                 const float v = __fadd_rn(__fadd_rn(__fadd_rn(lab[k][0] == c ? w[k][0] : 0.f, lab[k][1] == c ? w[k][1] : 0.f),
                                                     lab[k][2] == c ? w[k][2] : 0.f), lab[k][3] == c ? w[k][3] : 0.f);
@@ -408,8 +411,8 @@ extern "C" int cf_warp_labels_2d(const float* flow, const uint8_t* labels, uint8
     long n = (long)T * B * H * W;
     const double bytes = 10.0 * n;   // flow read (8 B), one label gathered (1 B) and one written (1 B) per pixel
     if (warp_v4(W, 8.0 * n))
-        launch_profiled(PK_WARP_LABELS, bytes, warp_labels_2d_v4_kernel, dim3(flat_grid(n / 4, 256)), dim3(256), as_stream(stream), flow,
-                        labels, out, T, B, K, H, W);
+        launch_profiled(PK_WARP_LABELS, bytes, K == 4 ? warp_labels_2d_v4_kernel<4> : warp_labels_2d_v4_kernel<0>, dim3(flat_grid(n / 4, 256)),
+                        dim3(256), as_stream(stream), flow, labels, out, T, B, K, H, W);
     else
         launch_profiled(PK_WARP_LABELS, bytes, warp_labels_2d_kernel, dim3(flat_grid(n, 256)), dim3(256), as_stream(stream), flow, labels,
                         out, T, B, K, H, W);
