@@ -43,7 +43,7 @@ struct F16sGeom {
     int ostep;               // patch step between output pixels (stride, or 1 for 1x1 convs)
     int tiles_x, tiles_y, bgroups;
     int nchunk;
-    int ablate;              // timing experiments only (CF_F16S_ABLATE): 1 = every chunk reads chunk 0's weight fragments (L1-resident), 2 = no fragment loads
+    int ablate;              // timing experiments only (CF_F16S_ABLATE): 1 = every chunk reads chunk 0's weight fragments (L1-resident), 2 = no fragment loads, 3 = no output stores
     int c1_pad;              // C1 rounded up to a multiple of CK: chunks below it read x1, the others x2 (the packed weights follow the same split)
     int NQ;                  // vector staging: 16-byte column quads per patch row (0: scalar staging)
     // magic multipliers floor(2^32/d)+1 for the index decodes (exact for n < 2^32/d; d == 1 handled apart): the kernel's setup was
@@ -644,6 +644,9 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
             const bool ok = o_ok[nt] && co_ok;
             float v = acc1[nt][r];
             if (p.res) { if (ok) v += p.res[r_off[nt] + (long)co * HoWo]; }   // rare (SingleConv / Linear residuals)
+#ifdef CF_F16S_ABLATION_BUILD
+            if (g.ablate != 3 || v == 12345.678f)      // CF_F16S_ABLATE=3: no output stores (upper bound of what hiding them could give)
+#endif
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, o_off[nt] + ochan, 0, 0);
             const float m = ok ? v : 0.f;
             ssum[r] += m;
