@@ -201,7 +201,10 @@ class Processor:
         nonempty = (ops.frame_boxes(x.view(T, H, W))[:, 0] >= 0)                  # frames with a non-zero pixel
         flat = x.view(T, 1, H * W)
         ops.group_norm(flat, None, None, 1, eps=0.0, out=flat)                    # per-frame z-score (population std), in place
-        x[~nonempty] = 0                                                          # 0 / 0 of an all-zero frame: keep NaN out of the batch
+        # a constant frame has std 0: monai's NormalizeIntensity then divides by 1 (-> all zeros), the kernel's 0 * inf is NaN.  Every
+        # z-scored frame that is not finite is such a frame: it becomes zeros, which is also what keeps the all-zero frame out of the batch
+        const = ~torch.isfinite(flat.view(T, -1)[:, 0])
+        x[const | ~nonempty] = 0
         logits = self.cropping_network(x)["pred"]
         lab = ops.argmax_channels(logits.contiguous())                            # softmax is monotone: argmax of the logits
         lab[~nonempty] = 0

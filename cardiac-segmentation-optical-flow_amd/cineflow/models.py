@@ -76,6 +76,11 @@ class SepConvGRU(Module):
         self.convr2 = Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
         self.convq2 = Conv2d(c, hidden_dim, (5, 1), padding=(2, 0))
 
+    def _prepare(self):
+        # the fused [r | z] tensors are built lazily from the children's weights: a (re)load must not keep the previous checkpoint's
+        for k in [k for k in self.__dict__ if k.startswith("_rz_")]:
+            del self.__dict__[k]
+
     def _fused(self, cr, cz, c1):
         """[r | z] gate convolution of one pass as ONE layer (weights concatenated on Cout): packed for the f16-split kernel
         (split-aware for cat[h, x]) and, for CONV_MODE 'f32', as the fp32 kernel's transposed matrix."""
@@ -122,6 +127,9 @@ class BasicUpdateBlock(Module):
         self.gru = SepConvGRU(hidden_dim=hidden_dim, input_dim=128 + hidden_dim)
         self.flow_head = FlowHead(hidden_dim, hidden_dim=256)
         self.mask = {0: Conv2d(128, 256, 3, padding=1), 2: Conv2d(256, 64 * 9, 1, padding=0)}
+
+    def _prepare(self):
+        self.__dict__.pop("_mask_scaled", None)      # derived from mask.2.bias on first use: dropped on every (re)load
 
     def forward(self, net, inp_motion, corr, flow):
         """inp_motion: [B,256,h,w] buffer whose first 128 channels hold `inp`; the motion features are written

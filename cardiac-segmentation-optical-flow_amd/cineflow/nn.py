@@ -108,7 +108,10 @@ class Conv2d(Module):
         if (x2 is None and act is None and res is None and out is None and ops.CONV_MODE == "f16s"
                 and ops.small_cin_supported(self.cin, self.ks[0], self.ks[1], self.stride, self.pad, stats_groups)):
             return ops.conv2d_small_cin(x, self._p["weight"], self._p.get("bias"), stats_groups)      # the stems: direct fp32, HBM-bound
-        if self._f16s and ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, x2, self.ks[0]):
+        Ho = (x.shape[2] + 2 * self.pad[0] - self.ks[0]) // self.stride + 1
+        Wo = (x.shape[3] + 2 * self.pad[1] - self.ks[1]) // self.stride + 1
+        if self._f16s and ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, x2, self.ks[0], out_sample_elems=(self.cout if out is None else out.shape[1]) * Ho * Wo,
+                                                                           out_hw=Ho * Wo):
             wpk, wsc = self._packed(x, x2)
             return ops.conv2d_f16s(x, wpk, wsc, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad,
                                    x2=x2, act=act, res=res, out=out, out_coff=out_coff, stats_groups=stats_groups)
@@ -135,7 +138,8 @@ class ConvTranspose2d(Module):
             self._wpk, self._ws = ops.pack_conv_weight_f16s(w.permute(1, 2, 3, 0).reshape(self.cout * 4, self.cin, 1, 1))
 
     def forward(self, x, out=None, out_coff=0, stats_groups=None):
-        if ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, None, 1):
+        if ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, None, 1, out_sample_elems=(self.cout if out is None else out.shape[1]) * 4 * x.shape[2] * x.shape[3],
+                                                           out_hw=x.shape[2] * x.shape[3]):
             return ops.conv_transpose2d_k2s2_f16s(x, self._wpk, self._ws, self._p.get("bias"), self.cout, out=out, out_coff=out_coff,
                                                   stats_groups=stats_groups)
         y = ops.conv_transpose2d_k2s2(x, self._p["weight"], self._p.get("bias"), out=out, out_coff=out_coff)

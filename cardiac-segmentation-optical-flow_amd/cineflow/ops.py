@@ -173,11 +173,15 @@ def f16s_chunk(kh, kw):
     return 16 if (kh, kw) == (3, 3) else 32
 
 
-def f16s_dynamic_ok(x1, x2, kh, kw=None):
-    """Run-time limit of conv_f16s.hip: one sample of each input below 2 GiB (32-bit buffer offsets; larger BATCHES are split inside
-    the library).  A cat[x1, x2] whose split is not a chunk multiple is handled by split-aware weight packing
+def f16s_dynamic_ok(x1, x2, kh, kw=None, out_sample_elems=None, out_hw=None):
+    """Run-time limits of conv_f16s.hip (conv_f16s_supported): one sample of each input below 2 GiB (32-bit buffer offsets; larger BATCHES
+    are split inside the library) and -- when the caller passes them -- one output sample (all `out_ctotal` channels of the destination
+    buffer, x4 for the transposed convolution's scatter) below 1 GiB, 8 of them when an output image has <= 256 pixels (the epilogue's
+    32-bit store offsets).  A cat[x1, x2] whose split is not a chunk multiple is handled by split-aware weight packing
     (pack_conv_weight_f16s(w, c1=...)), not by another kernel."""
     per = lambda t: 0 if t is None else (t.numel() // t.shape[0]) * 4
+    if out_sample_elems is not None and out_sample_elems * 4 * (8 if (out_hw is not None and out_hw <= 256) else 1) >= 2 ** 30:
+        return False
     return per(x1) < 2 ** 31 and per(x2) < 2 ** 31
 
 

@@ -87,6 +87,8 @@ class CineTrainer:
         self.seg_net.load_state_dict(params["seg_state_dict"], self.device)
         self.flow_net.load_state_dict(params["flow_state_dict"], self.device)
         if self.crop_net is not None:
+            if "crop_state_dict" not in params:
+                raise KeyError("plans['cropping_net'] is set but the checkpoint has no 'crop_state_dict' (save_model_folder(..., crop_sd=...))")
             self.crop_net.load_state_dict(params["crop_state_dict"], self.device)
 
     # -- nnUNetTrainer.py:571-597 preprocess_patient(list_of_files) -> (data[C,Z,Y,X], seg, properties)

@@ -21,8 +21,10 @@ box; `determine_postprocessing_custom` (connected_components.py:574-596) then ke
 
 `write_raw` is the producer side: it writes that `Raw/` tree and the `.pkl` files from the outputs of
 `CineTrainer.predict_preprocessed_data_return_seg_and_softmax_flow` (`cineflow.predict.set_voxelmorph_raw(pred_path, pkl_path)`, CLI
-`--voxelmorph_raw`).  The `.pkl` files hold plain Python / numpy values only and are written with `pickle.dump`; nothing in the
-build un-pickles a file it did not write itself.
+`--voxelmorph_raw`).  The `.pkl` files hold plain Python / numpy values only and are written with `pickle.dump`.  The consumer reads
+them with `_PlainUnpickler`, whose `find_class` admits OrderedDict and numpy's array / dtype / scalar reconstructors and nothing else:
+a `.pkl` tree written by the reference pipeline loads (its properties are exactly such values), a pickle that names any other
+global raises `pickle.UnpicklingError` instead of importing or calling it.
 monai and nibabel are absent here: ResizeWithPadOrCrop is restated from its documented centre rule (parity unpinned), NIfTI goes
 through cineflow.nifti in nibabel's (i, j, k) axis order.
 """
@@ -42,6 +44,29 @@ join = os.path.join
 
 
 # ------------------------------------------------------------------------------------------------ small pieces
+class _PlainUnpickler(pickle.Unpickler):
+    """pickle.Unpickler that can only rebuild plain containers and numpy values (what nnU-Net property dicts hold).  `pkl_path` is a free
+    CLI argument and its natural input is a tree another pipeline wrote, so no global outside this list is ever resolved."""
+
+    _ALLOWED = {
+        ("collections", "OrderedDict"),
+        ("numpy", "ndarray"), ("numpy", "dtype"),
+        ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+        ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+        ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+    }
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError("refusing to load global %s.%s from a properties .pkl (plain containers and numpy values only)" % (module, name))
+
+
+def load_plain_pickle(path):
+    with open(path, "rb") as f:
+        return _PlainUnpickler(f).load()
+
+
 def delete_if_exist(folder_name):
     """voxelmorph_saver_Lib.py:279-282."""
     if os.path.isdir(folder_name):
@@ -165,8 +190,7 @@ class Saver:
 
     @staticmethod
     def _load_pkl(pkl_path, fname):
-        with open(join(pkl_path, fname + ".pkl"), "rb") as f:   # written by write_raw above (plain values)
-            properties = pickle.load(f)
+        properties = load_plain_pickle(join(pkl_path, fname + ".pkl"))     # plain values only: anything else raises UnpicklingError
         return properties, np.asarray(properties["padding_need"]), list(properties["voxelmorph_size_before"])
 
     def postprocess(self, pred_path_list_registered, pred_path_list_seg, pred_path_list_flow, pred_path_list_seg_ed, pkl_path,

@@ -127,8 +127,9 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     // Inputs are read with raw buffer loads: the per-lane 32-bit byte offset of (sample, channel 0, iy, ix) is computed
     // once per task, the channel term is added per load, and the descriptor's range check returns 0 for (a) pixels
     // outside the image / batch, whose offset is parked at 2 GiB, and (b) channel reads past the end of the tensor.
-    // (Channels >= Cin that still fall inside the tensor read finite data of the next sample; their packed weights are
-    // exactly zero.)  Host checks: tensors < 2 GiB, and C1 % CK == 0 when x2 is present.
+    // (c) the padded channel tail of each input -- channels [C1, c1_pad) of x1 and [C2, ...) of x2, whose packed weights are exactly
+    // zero: their loads are parked out of range too (issue_loads*), so a NaN / Inf in the NEXT sample's first channels cannot reach this
+    // sample as NaN * 0.  Host checks: one sample of each tensor < 2 GiB (split-aware packing handles any C1 when x2 is present).
     constexpr unsigned OOB = 0x80000000u;
     unsigned t_o1[MAXT], t_o2[MAXT];  // byte offsets into x1 / x2 (OOB when invalid)
     int t_lds[MAXT];                  // byte offset of the 16-byte hi slot inside a buffer, -1: no task
@@ -171,12 +172,13 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
         const int c0 = chunk * CK;
         const bool in1 = c0 < g.c1_pad;                   // workgroup-uniform; c1_pad = C1 rounded up to whole chunks (split-aware packing)
         const unsigned cb = (unsigned)(in1 ? c0 : c0 - g.c1_pad);
+        const unsigned clim = (unsigned)(in1 ? p.C1 : p.C2);   // channels at or past it are the zero-weight tail: never fetched (a select, not a branch)
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             const unsigned v0 = (in1 ? t_o1[t] : t_o2[t]) + (cb + t_g8[t]) * HW4;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const unsigned off = v0 + (unsigned)j * HW4;
+                const unsigned off = (cb + t_g8[t] + (unsigned)j < clim) ? v0 + (unsigned)j * HW4 : OOB;
                 const unsigned raw = in1 ? __builtin_amdgcn_raw_buffer_load_b32(rsrc1, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b32(rsrc2, off, 0, 0);
                 stg[t][j] = __builtin_bit_cast(float, raw);
             }
@@ -245,12 +247,13 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
         const int c0 = chunk * CK;
         const bool in1 = c0 < g.c1_pad;
         const unsigned cb = (unsigned)(in1 ? c0 : c0 - g.c1_pad);
+        const unsigned clim = (unsigned)(in1 ? p.C1 : p.C2);
 #pragma unroll
         for (int t = 0; t < VT; ++t) {
             const unsigned v0 = (in1 ? v_o1[t] : v_o2[t]) + (cb + v_c4[t]) * HW4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned off = v0 + (unsigned)j * HW4;
+                const unsigned off = (cb + v_c4[t] + (unsigned)j < clim) ? v0 + (unsigned)j * HW4 : OOB;
                 stg[t][j] = in1 ? __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc1, off, 0, 0))
                                 : __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, 0, 0));
             }
@@ -892,6 +895,10 @@ bool conv_f16s_supported(const ConvParams& p) {
     if (!f16s_kind(p)) return false;
     const long HW = (long)p.H * p.W;
     if ((long)p.C1 * HW * 4 >= (1L << 31) || (long)p.C2 * HW * 4 >= (1L << 31)) return false;
+    // the epilogue's buffer-resource stores address the output samples of one workgroup with 32-bit offsets below 1 GiB (launch_f16s_v):
+    // up to 8 whole images per workgroup when an image fits one tile (<= 256 pixels), else one
+    const double osample = (double)p.out_ctotal * p.Ho * p.Wo * (p.scatter2x2 ? 4.0 : 1.0) * 4.0;
+    if (osample * ((long)p.Ho * p.Wo <= 256 ? 8.0 : 1.0) >= 1073741824.0) return false;
     return true;
 }
 

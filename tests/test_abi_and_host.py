@@ -183,3 +183,54 @@ def test_shard_is_the_reference_partition():
     parts = [shard(items, r, 4) for r in range(4)]
     assert parts[1] == items[1::4]
     assert sorted(sum(parts, [])) == items
+
+
+def test_properties_pkl_reader_rebuilds_plain_values_and_refuses_globals(tmp_path):
+    """the voxelmorph_saver consumer reads <pkl_path>/<case>.pkl files another pipeline may have written -- nnU-Net property
+    dicts (OrderedDict, lists, tuples, numpy arrays / scalars) load, any other global is refused before it is imported or called."""
+    import collections
+    import pickle
+    from cineflow.voxelmorph_saver import load_plain_pickle
+    props = collections.OrderedDict(original_size_of_raw_data=np.array([10, 256, 216]), original_spacing=np.array([10.0, 1.25, 1.25]),
+                                    list_of_data_files=["a_0000.nii.gz"], itk_spacing=(1.25, 1.25, 10.0), crop_bbox=[[0, 10], [0, 256], [0, 216]],
+                                    classes=np.array([0, 1, 2, 3], dtype=np.int16), size_after_cropping=(10, 256, 216), use_nonzero_mask_for_norm={0: False},
+                                    padding_need=np.arange(40, dtype=np.int64).reshape(4, 10), voxelmorph_size_before=[256, 216, 10],
+                                    a_scalar=np.float64(1.5), an_int_scalar=np.int32(7))
+    ok = tmp_path / "ok.pkl"
+    with open(ok, "wb") as f:
+        pickle.dump(props, f)
+    got = load_plain_pickle(str(ok))
+    assert list(got.keys()) == list(props.keys())
+    assert np.array_equal(got["padding_need"], props["padding_need"]) and got["a_scalar"] == 1.5 and got["itk_spacing"] == (1.25, 1.25, 10.0)
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > %s" % (tmp_path / "pwned"),))
+
+    bad = tmp_path / "bad.pkl"
+    with open(bad, "wb") as f:
+        pickle.dump({"padding_need": np.zeros((4, 1)), "x": Evil()}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        load_plain_pickle(str(bad))
+    assert not (tmp_path / "pwned").exists()
+
+
+def test_conv_f16s_output_sample_limit_falls_back_to_fp32_kernel():
+    """a destination buffer whose sample exceeds the epilogue's 32-bit store range makes f16s_dynamic_ok say no (the layer then
+    takes the exact fp32 kernel) instead of raising from inside the library.  Host logic only."""
+    from cineflow import ops
+
+    class Fake:
+        def __init__(self, shape):
+            self.shape = shape
+
+        def numel(self):
+            n = 1
+            for v in self.shape:
+                n *= v
+            return n
+    x = Fake((1, 16, 4096, 4096))                                            # 1 GiB input sample: fine (< 2 GiB)
+    assert ops.f16s_dynamic_ok(x, None, 3, out_sample_elems=8 * 4096 * 4096, out_hw=4096 * 4096)
+    assert not ops.f16s_dynamic_ok(x, None, 3, out_sample_elems=16 * 4096 * 4096, out_hw=4096 * 4096)      # 1 GiB output sample
+    assert not ops.f16s_dynamic_ok(Fake((1, 8, 16, 16)), None, 3, out_sample_elems=2 ** 25, out_hw=256)      # 8 images per workgroup

@@ -203,6 +203,22 @@ def test_raft_loop_vs_oracle(dev):
     assert epe <= 1e-4, "mean EPE %.3e px (|flow| mean %.3f)" % (epe, float(ref.abs().mean()))
 
 
+def test_raft_net_reloaded_with_other_weights_matches_a_fresh_net(dev):
+    """SepConvGRU's fused [r | z] gate weights and BasicUpdateBlock's scaled mask bias are derived on first use; a second
+    load_state_dict on the same net (fold loop of predict_non_flow, user code) must drop them -- same numbers as a net built fresh."""
+    from cineflow.models import SegFlowGaussian
+    kw = dict(image_size=128, in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=256, bottleneck_heads=4, dim_feedforward=64,
+              motion_appearance=False, raft=True, raft_iters=2)
+    frames = randn(2, 1, 1, 128, 128, seed=39).to(dev)
+    m = load(SegFlowGaussian(**kw), 13, dev)
+    first = m(frames)["backward_flow"].clone()
+    load(m, 14, dev)                                             # other weights into the SAME object
+    again = m(frames)["backward_flow"]
+    fresh = load(SegFlowGaussian(**kw), 14, dev)(frames)["backward_flow"]
+    assert float((again - fresh).abs().max()) == 0.0
+    assert float((again - first).abs().max()) > 0.0
+
+
 def test_full_width_blocks_vs_oracle(dev):
     """Full-width (raft_config.yaml dims) single blocks at 256x256 against the oracle on the same seeded weights."""
     from cineflow.nn import ConvBlocks2DGroupLegacy, CrossAttentionLayer, ConvGRUCell
@@ -468,6 +484,7 @@ def test_processor_centroid_vs_oracle(dev):
     oproc = OM.Processor(32, 64, lambda x: {"pred": onet(x)})
     frames = smooth_cine(6, 1, 64, 21)[:, 0] * 40 + 90          # [T,1,64,64]
     frames[2] = 0                                               # an all-zero frame: no network, empty mask
+    frames[4] = 7.0                                             # a constant non-zero frame: std 0 -> only the mean is subtracted (zeros into the network, no NaN)
     cen, lab = proc.preprocess_no_registration(frames.to(dev))
     from oracle import ops as OO
     with torch.no_grad():
@@ -479,6 +496,7 @@ def test_processor_centroid_vs_oracle(dev):
     keep = [t for t in range(6) if t != 2]
     assert float(sure.float().mean()) > 0.5
     assert bool((lab.cpu().long()[keep][sure] == olab[keep][sure]).all()) and int(lab[2].max()) == 0 and int(olab[2].max()) == 0
+    assert bool(sure[keep.index(4)].any()), "the constant frame must be compared somewhere"
     if float((lab.cpu().long() == olab).float().mean()) == 1.0:
         assert cen.tolist() == ocen.tolist()
     assert proc.get_mean_centroid(olab.to(torch.uint8).to(dev)).tolist() == ocen.tolist()

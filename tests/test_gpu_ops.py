@@ -402,6 +402,29 @@ def test_conv2d_f16s_nonfinite_inputs_propagate(dev):
     assert torch.isfinite(out[0, :, 0, 4:]).all()
 
 
+@pytest.mark.parametrize("C1,C2,H,W,k", [(6, 0, 16, 16, 3), (20, 12, 16, 16, 3), (20, 12, 13, 18, 3), (40, 24, 16, 16, 1), (30, 0, 64, 64, 3)])
+def test_conv2d_f16s_channel_tail_never_reads_the_next_sample(dev, C1, C2, H, W, k):
+    """the padded channel tail [C, chunk multiple) of sample b used to be fetched from the first channels of sample b + 1 (against
+    zero weights): a NaN there became NaN * 0 in sample b.  The tail loads are parked out of range now: sample 0 of a batch whose sample 1 is
+    all NaN / Inf equals sample 0 computed alone, bit for bit (vector, scalar and 1x1 staging; single input and cat[x1, x2])."""
+    from cineflow import ops
+    Cout = 24
+    x1 = randn(2, C1, H, W, seed=60)
+    x2 = randn(2, C2, H, W, seed=61) if C2 else None
+    w = randn(Cout, C1 + C2, k, k, seed=62) / math.sqrt((C1 + C2) * k * k)
+    wpk, ws = ops.pack_conv_weight_f16s(w.to(dev), c1=C1 if C2 else None)
+    pad = (k // 2, k // 2)
+    d = lambda t: None if t is None else t.to(dev)
+    clean = ops.conv2d_f16s(d(x1[:1].contiguous()), wpk, ws, None, Cout, k, k, 1, pad, x2=d(None if x2 is None else x2[:1].contiguous()))
+    x1[1] = float("nan")
+    if x2 is not None:
+        x2[1] = float("inf")
+    both = ops.conv2d_f16s(d(x1), wpk, ws, None, Cout, k, k, 1, pad, x2=d(x2))
+    assert torch.isfinite(both[0]).all(), "sample 0 poisoned by sample 1's values through the channel tail"
+    assert torch.equal(both[0], clean[0])
+    assert torch.isnan(both[1]).all()
+
+
 @pytest.mark.parametrize("B,Cin,H,W,Cout,k,stride,groups", [
     (2, 16, 32, 32, 64, 3, 1, 8),      # GroupNorm(8, 64): 8 channels per group
     (3, 32, 64, 64, 32, 3, 1, 32),     # InstanceNorm (one channel per group), narrow kernel variant
