@@ -13,7 +13,13 @@ Differences that are deliberate and documented in DESIGN.md:
   * preprocessing is the z-score of the volume at native spacing (crop-to-nonzero and resampling are the "next" rows
     of SURVEY.md section 8f), so the exporter needs no resampling either; the heart centroid of `Processor` comes from
     the image centre because the reference's 2-class cropping network is outside this path (SURVEY row a20);
-  * when no ED label map is supplied the ED segmentation predicted by the U-Net is the one propagated.
+  * when no ED label map is supplied the ED segmentation predicted by the U-Net is the one propagated;
+  * `predict_from_folder` loads the model once and fills the device batch ACROSS patients: the cropped slices of as many patients as fit
+    `MAX_SLICES_PER_LAUNCH` (64) go through the networks as one batch (`CineTrainer.predict_patients_flow`), the next group's files are
+    read and preprocessed by the `num_threads_preprocessing` pool meanwhile, and the NIfTI / NPZ export of finished patients runs in the
+    `num_threads_nifti_save` pool while the device works on the next group.  The reference predicts and exports patient by patient
+    (predict.py:228-354, :1008-1110); per-patient results are those of the one-patient call up to the launch shapes the batch size
+    selects (tests/test_predict_api.py asserts the bound).  `LAST_TIMING` holds the wall-time split of the last call.
 """
 import argparse
 import csv
@@ -32,6 +38,9 @@ from .models import Generic_UNet, SegFlowGaussian
 from .nifti import read_nifti, write_nifti
 
 join = os.path.join
+
+MAX_SLICES_PER_LAUNCH = int(os.environ.get("CF_API_SLICES", "64"))   # cropped cine slices per device batch of the file-level API
+LAST_TIMING = {}                                                     # wall-time split of the last predict_from_folder / predict_cases call
 
 
 # ------------------------------------------------------------------------------------------------ model folder
@@ -55,32 +64,79 @@ def default_plans(image_size=256, crop_size=None, flow_variant="video", seg_base
     return p
 
 
-class CineTrainer:
-    """Duck-types the trainer interface `predict_cases` uses (predict.py:285-354, :1028-1091)."""
+def _config_values(spec, model_folder, reader):
+    """a config given inline (the YAML's mapping) or as a file name, absolute or relative to the model folder"""
+    if isinstance(spec, dict):
+        return spec
+    path = spec if os.path.isabs(spec) or model_folder is None else join(model_folder, spec)
+    return reader(path)
 
-    def __init__(self, plans, device):
+
+class ModelWrapFlow:
+    """ModelWrap (successive.yaml: Optical_flow_model_successive.py:58-134) behind the flow-network interface of predict_cine_slices:
+    __call__(x [T,B,1,H,W]) -> {'backward_flow': ED->t cumulative flow [T-1,B,2,H,W]} (out2['cumulated'], or model1's single pair flow
+    when T == 2, :95-96)."""
+    num_classes = 4
+
+    def __init__(self, wrap):
+        self.wrap = wrap
+
+    def __call__(self, x):
+        _out1, out2 = self.wrap(x, inference=False)
+        return {"backward_flow": out2["cumulated"] if x.shape[0] > 2 else out2["flow"][None]}
+
+    def state_shapes(self):
+        return self.wrap.state_shapes()
+
+    def load_state_dict(self, sd, device, **kw):
+        self.wrap.load_state_dict(sd, device, **kw)
+        return self
+
+
+class CineTrainer:
+    """Duck-types the trainer interface `predict_cases` uses (predict.py:285-354, :1028-1091).
+
+    plans['flow_net'] selects the flow network either the build's short way, {'variant': 'video' | 'raft_config', 'kwargs': {...}}, or the
+    reference's way, {'config': <mapping of the YAML's values, or a file name such as 'config.yaml' in the model folder>}: that config goes
+    through cineflow.config (`read_config_video` + `build_seg_flow_gaussian_model` / the successive pair), as run_training.py:191 does with
+    `<weights>/config.yaml`.  `prediction: false` is supplied when the file lacks it (raft_config.yaml).
+    plans['cropping_net'] = {'type': 'mtl', 'config': <adversarial_acdc.yaml values or file name>, 'window_size': 7} puts the reference's own
+    cropping network -- MTLmodel(num_classes=2), voxelmorph_saver_Lib.py:340-348 -- into the Processor; {'base_num_features', 'num_pool'}
+    keeps the 2-class Generic_UNet stand-in of round 2."""
+
+    def __init__(self, plans, device, model_folder=None):
         self.plans = plans
         self.device = device
         self.num_classes = plans["num_classes"]
         self.data_aug_params = {"mirror_axes": tuple(plans["mirror_axes"])}
         self.patch_size = tuple(plans["patch_size"])
         self.processor = Processor(crop_size=plans["crop_size"], image_size=plans["patch_size"][0])
-        # the Processor's 2-class cropping network (processor.py:162-176).  The reference builds an MTLmodel from adversarial_acdc.yaml
-        # (voxelmorph_saver_Lib.py:328-335); plans['cropping_net'] = {'base_num_features', 'num_pool'} puts a 2-class Generic_UNet in its
-        # place (a documented stand-in: the centroid ARITHMETIC around it is the reference's, the network is not the same architecture)
         self.crop_net = None
         ck = plans.get("cropping_net")
         if ck:
             from .inference import CroppingNet
-            self.crop_net = Generic_UNet(1, ck["base_num_features"], 2, ck["num_pool"])
-            self.processor.cropping_network = CroppingNet(self.crop_net)
+            if ck.get("type") == "mtl":
+                from . import config as C
+                cfg = _config_values(ck["config"], model_folder, lambda f: C.read_config(f, False, False))
+                self.crop_net = C.build_2d_model(cfg, conv_layer=None, norm=None, log_function=None, image_size=plans["patch_size"][0],
+                                                 window_size=ck["window_size"], middle=False, num_classes=2, processor=None)
+                self.processor.cropping_network = self.crop_net            # MTLmodel.forward returns {'pred': logits} itself
+            else:
+                self.crop_net = Generic_UNet(1, ck["base_num_features"], 2, ck["num_pool"])
+                self.processor.cropping_network = CroppingNet(self.crop_net)
         sk = plans["seg_net"]
         self.seg_net = Generic_UNet(plans["num_modalities"], sk["base_num_features"], self.num_classes, sk["num_pool"])
         fk = plans["flow_net"]
-        ma = fk["variant"] == "raft_config"
-        kw = dict(image_size=plans["crop_size"], motion_appearance=ma, dim_feedforward=3072 if ma else 2048)
-        kw.update(fk.get("kwargs", {}))
-        self.flow_net = SegFlowGaussian(**kw)
+        if fk.get("config") is not None:
+            from . import config as C
+            cfg = C.with_defaults(_config_values(fk["config"], model_folder, C.read_config_video), prediction=False)
+            net = C.build_flow_net(cfg, image_size=plans["crop_size"])
+            self.flow_net = ModelWrapFlow(net) if not isinstance(net, SegFlowGaussian) else net
+        else:
+            ma = fk["variant"] == "raft_config"
+            kw = dict(image_size=plans["crop_size"], motion_appearance=ma, dim_feedforward=3072 if ma else 2048)
+            kw.update(fk.get("kwargs", {}))
+            self.flow_net = SegFlowGaussian(**kw)
 
     # -- network_trainer.py:418 load_checkpoint_ram(params, train)
     def load_checkpoint_ram(self, params, train=False):
@@ -126,17 +182,8 @@ class CineTrainer:
                                        mirror_axes=mirror_axes, use_gaussian=use_gaussian, pad_border_mode=pad_border_mode,
                                        pad_kwargs=pad_kwargs)
 
-    # -- nnUNetTrainer.py:682-726 -> SegFlowGaussian.predict_3D_flow :2837, _internal_predict_2D_2Dconv_tiled_flow :3294-3533
-    def predict_preprocessed_data_return_seg_and_softmax_flow(self, unlabeled, target=None, target_mask=None, processor=None,
-                                                              do_mirroring=True, mirror_axes=None, use_sliding_window=True, step_size=0.5,
-                                                              use_gaussian=True, pad_border_mode="constant", pad_kwargs=None,
-                                                              all_in_gpu=False, verbose=True, mixed_precision=True, centroid=None, return_crop=False):
-        """unlabeled [T,1,Z,Y,X] (numpy) -> (seg [T,Z,Y,X], softmax [T,K,Z,Y,X], flow [T,2,Z,Y,X], registered [T,1,Z,Y,X],
-        raw [T,3,Z,crop,crop]).  target: optional ED label volume [Z,Y,X].  centroid: (x, y) of the heart in the patch, or None (patch
-        centre).  return_crop=True appends the crop-space results the voxelmorph_saver layout stores: dict(softmax [T,K,Z,c,c],
-        flow [T,2,Z,c,c], registered [T,Z,c,c], padding_need [4,Z], size_before [Y,X,Z])."""
-        processor = processor or self.processor
-        mirror_axes = self.data_aug_params["mirror_axes"] if mirror_axes is None else mirror_axes
+    # -- SegFlowGaussian.py:3294-3533 up to the network call: pad, centre crop to the patch, heart-centred crop, z-score
+    def _flow_prepare(self, unlabeled, target, processor, pad_border_mode, pad_kwargs, centroid):
         T, _, Z, Y, X = unlabeled.shape
         P = self.patch_size
         x = unlabeled[:, 0]                                                            # [T,Z,Y,X]
@@ -164,15 +211,20 @@ class CineTrainer:
             blk = ops.crop2d(patch[:, z].contiguous(), cy0, cx0, cs, cs)               # [T,cs,cs]
             normalize_intensity_(blk)                                                   # :3108 NormalizeIntensity on the slice's [T,h,w] block
             crop[:, z] = blk
-        frames = crop.view(T, Z, 1, cs, cs)
         ed = None
         if target is not None:
             tp = pad_nd_image(np.asarray(target)[None], P, "constant", {"constant_values": 0}, False)[0]
             tp = tp[:, y1:y2, x1:x2]
             ed = torch.from_numpy(np.ascontiguousarray(np.stack([tp[z, wins[z]["crop_indices"][2]:wins[z]["crop_indices"][3],
                                                                     wins[z]["crop_indices"][0]:wins[z]["crop_indices"][1]] for z in range(Z)]))).to(dev, dtype=torch.uint8)
-        out = predict_cine_slices(self.flow_net, self.seg_net, frames, ed, do_mirroring, mirror_axes)
         pad_need = np.stack([np.asarray(w["padding_need"], dtype=np.int64) for w in wins], axis=1)     # [4, Z]
+        return {"frames": crop.view(T, Z, 1, cs, cs), "ed": ed, "pad_need": pad_need, "slicer": slicer, "geom": (T, Z, Y, X, Hp, Wp, y1, y2, x1, x2),
+                "processor": processor}
+
+    # -- :3427-3467 after the network call: per-slice uncrop, centre window, un-pad, host copies
+    def _flow_finish(self, prep, out, return_crop):
+        T, Z, Y, X, Hp, Wp, y1, y2, x1, x2 = prep["geom"]
+        processor, pad_need, slicer, frames, dev = prep["processor"], prep["pad_need"], prep["slicer"], prep["frames"], self.device
 
         def place(t):  # [T, C?, Z, cs, cs] -> [..., Z, Y, X]: per-slice uncrop (processor.py:178-186), centre window, un-pad
             zax = t.dim() - 3
@@ -194,6 +246,46 @@ class CineTrainer:
             return res + (crop_out,)
         return res
 
+    # -- nnUNetTrainer.py:682-726 -> SegFlowGaussian.predict_3D_flow :2837, _internal_predict_2D_2Dconv_tiled_flow :3294-3533
+    def predict_preprocessed_data_return_seg_and_softmax_flow(self, unlabeled, target=None, target_mask=None, processor=None,
+                                                              do_mirroring=True, mirror_axes=None, use_sliding_window=True, step_size=0.5,
+                                                              use_gaussian=True, pad_border_mode="constant", pad_kwargs=None,
+                                                              all_in_gpu=False, verbose=True, mixed_precision=True, centroid=None, return_crop=False):
+        """unlabeled [T,1,Z,Y,X] (numpy) -> (seg [T,Z,Y,X], softmax [T,K,Z,Y,X], flow [T,2,Z,Y,X], registered [T,1,Z,Y,X],
+        raw [T,3,Z,crop,crop]).  target: optional ED label volume [Z,Y,X].  centroid: (x, y) of the heart in the patch, or None (patch
+        centre).  return_crop=True appends the crop-space results the voxelmorph_saver layout stores: dict(softmax [T,K,Z,c,c],
+        flow [T,2,Z,c,c], registered [T,Z,c,c], padding_need [4,Z], size_before [Y,X,Z])."""
+        return self.predict_patients_flow([unlabeled], [target], processor=processor, do_mirroring=do_mirroring, mirror_axes=mirror_axes,
+                                          pad_border_mode=pad_border_mode, pad_kwargs=pad_kwargs, centroids=[centroid], return_crop=return_crop)[0]
+
+    def predict_patients_flow(self, unlabeled_list, targets=None, processor=None, do_mirroring=True, mirror_axes=None, pad_border_mode="constant",
+                              pad_kwargs=None, centroids=None, return_crop=False):
+        """The one-patient call above for several patients whose cropped slices share ONE device batch: every patient is padded / cropped /
+        z-scored on its own (`_flow_prepare`), the `[T, Z_p, 1, c, c]` stacks of the patients with the same frame count T are concatenated
+        on the slice axis, predict_cine_slices runs once per such group, and each patient's slices go back through its own un-crop
+        (`_flow_finish`).  No kernel mixes batch entries; results are those of the one-patient calls up to the launch shapes the batch
+        size selects.  Returns one result tuple per patient, in order."""
+        processor = processor or self.processor
+        mirror_axes = self.data_aug_params["mirror_axes"] if mirror_axes is None else mirror_axes
+        n = len(unlabeled_list)
+        targets = targets or [None] * n
+        centroids = centroids or [None] * n
+        preps = [self._flow_prepare(u, t, processor, pad_border_mode, pad_kwargs, c) for u, t, c in zip(unlabeled_list, targets, centroids)]
+        outs = [None] * n
+        by_T = {}
+        for i, pr in enumerate(preps):
+            by_T.setdefault((pr["frames"].shape[0], pr["ed"] is not None), []).append(i)
+        for (_T, has_ed), idx in by_T.items():
+            frames = preps[idx[0]]["frames"] if len(idx) == 1 else torch.cat([preps[i]["frames"] for i in idx], dim=1)
+            ed = None if not has_ed else (preps[idx[0]]["ed"] if len(idx) == 1 else torch.cat([preps[i]["ed"] for i in idx], dim=0))
+            out = predict_cine_slices(self.flow_net, self.seg_net, frames.contiguous(), ed, do_mirroring, mirror_axes)
+            z0 = 0
+            for i in idx:
+                Z = preps[i]["frames"].shape[1]
+                outs[i] = {k: v[:, z0:z0 + Z] for k, v in out.items()}
+                z0 += Z
+        return [self._flow_finish(pr, o, return_crop) for pr, o in zip(preps, outs)]
+
 
 def load_model_and_checkpoint_files(folder, folds=None, mixed_precision=None, checkpoint_name="model_final_checkpoint", device=None):
     """model_restore.py:109-155 equivalent for the plans.json / *.model folder format -> (trainer, [params per fold])."""
@@ -207,7 +299,7 @@ def load_model_and_checkpoint_files(folder, folds=None, mixed_precision=None, ch
     else:
         folds = ["fold_%s" % folds]
     device = device or torch.device("cuda", torch.cuda.current_device())
-    trainer = CineTrainer(plans, device)
+    trainer = CineTrainer(plans, device, model_folder=folder)
     params = [torch.load(join(folder, f, checkpoint_name + ".model"), map_location="cpu", weights_only=True) for f in folds]
     return trainer, params
 
@@ -399,19 +491,12 @@ def set_voxelmorph_raw(pred_path, pkl_path=None):
     _VOXELMORPH_RAW = None if pred_path is None else (pred_path, pkl_path or join(pred_path, "pkl"))
 
 
-def predict_flow(d, trainer, output_filenames, property_list, do_tta, mixed_precision, params, interpolation_order, force_separate_z,
-                 interpolation_order_z, all_in_gpu, step_size, save_npz, disable_postprocessing, model, pool):
-    """predict.py:1008-1162 for one patient: `d[t]` = preprocessed frame t (ED first), all frames form the cine sequence.
-    Writes <patient>/{Segmentation,Flow,Registered}/<case>; returns the three path lists.
-    After set_voxelmorph_raw(pred_path, pkl_path) the crop-space predictions are additionally written as `<pred_path>/Raw/...` +
-    `<pkl_path>/<case>.pkl`, the input layout of voxelmorph_saver_* (cineflow.voxelmorph_saver)."""
+def _export_flow_patient(result, trainer, output_filenames, property_list, interpolation_order, force_separate_z, interpolation_order_z,
+                         save_npz, pool):
+    """predict.py:1084-1110 for one patient's device results: transpose back, submit one export job per frame to the pool.
+    Returns (seg_paths, flow_paths, reg_paths, jobs)."""
     voxelmorph_raw = _VOXELMORPH_RAW
-    unlabeled = np.stack(d) + 1e-8                                               # predict.py:1025
-    print("predicting", output_filenames)
-    seg, softmax, flow, registered, _raw, crop_out = trainer.predict_preprocessed_data_return_seg_and_softmax_flow(
-        unlabeled=unlabeled, target=None, target_mask=None, processor=trainer.processor, do_mirroring=do_tta,
-        mirror_axes=trainer.data_aug_params["mirror_axes"], use_sliding_window=True, step_size=step_size, use_gaussian=True,
-        all_in_gpu=all_in_gpu, mixed_precision=mixed_precision, verbose=False, return_crop=True)
+    seg, softmax, flow, registered, _raw, crop_out = result
     assert len(softmax) == len(flow) == len(registered)
     if voxelmorph_raw is not None:
         from .voxelmorph_saver import write_raw
@@ -431,14 +516,24 @@ def predict_flow(d, trainer, output_filenames, property_list, do_tta, mixed_prec
         flow_paths.append(flow_path[:-7] + ".npz")
         reg_paths.append(reg_path)
         npz = seg_path[:-7] + ".npz" if save_npz else None
-        jobs.append(pool.apply_async(save_segmentation_nifti_from_softmax,
-                                     (softmax[t], seg_path, property_list[t], interpolation_order, None, None, None, npz, None,
-                                      force_separate_z, interpolation_order_z, False, flow[t], flow_paths[-1], registered[t], reg_path)))
-    print("inference done. Now waiting for the segmentation export to finish...")
-    [j.get() for j in jobs]
+        jobs.append(pool.apply_async(_timed_export, (softmax[t], seg_path, property_list[t], interpolation_order, None, None, None, npz, None,
+                                                     force_separate_z, interpolation_order_z, False, flow[t], flow_paths[-1], registered[t], reg_path)))
+    return seg_paths, flow_paths, reg_paths, jobs
+
+
+def _timed_export(*a):
+    import time
+    t0 = time.perf_counter()
+    save_segmentation_nifti_from_softmax(*a)
+    return time.perf_counter() - t0
+
+
+def _finish_flow_patient(seg_paths, reg_paths, jobs, output_filenames, disable_postprocessing, model):
+    """wait for a patient's export jobs, then predict.py:1139-1156 (largest-component filter when the model folder has a postprocessing.json)"""
+    work = sum(j.get() for j in jobs)
     if not disable_postprocessing:
         pp_file = join(model, "postprocessing.json")
-        if os.path.isfile(pp_file):                                              # predict.py:1139-1156
+        if os.path.isfile(pp_file):
             print("postprocessing...")
             shutil.copy(pp_file, os.path.abspath(os.path.dirname(output_filenames[0])))
             for_which_classes, min_valid_obj_size = load_postprocessing(pp_file)
@@ -446,6 +541,25 @@ def predict_flow(d, trainer, output_filenames, property_list, do_tta, mixed_prec
                 load_remove_save(pth, pth, for_which_classes, min_valid_obj_size)
         else:
             print("WARNING! Cannot run postprocessing because the postprocessing file is missing (%s)" % model)
+    return work
+
+
+def predict_flow(d, trainer, output_filenames, property_list, do_tta, mixed_precision, params, interpolation_order, force_separate_z,
+                 interpolation_order_z, all_in_gpu, step_size, save_npz, disable_postprocessing, model, pool):
+    """predict.py:1008-1162 for one patient: `d[t]` = preprocessed frame t (ED first), all frames form the cine sequence.
+    Writes <patient>/{Segmentation,Flow,Registered}/<case>; returns the three path lists.
+    After set_voxelmorph_raw(pred_path, pkl_path) the crop-space predictions are additionally written as `<pred_path>/Raw/...` +
+    `<pkl_path>/<case>.pkl`, the input layout of voxelmorph_saver_* (cineflow.voxelmorph_saver)."""
+    unlabeled = np.stack(d) + 1e-8                                               # predict.py:1025
+    print("predicting", output_filenames)
+    result = trainer.predict_preprocessed_data_return_seg_and_softmax_flow(
+        unlabeled=unlabeled, target=None, target_mask=None, processor=trainer.processor, do_mirroring=do_tta,
+        mirror_axes=trainer.data_aug_params["mirror_axes"], use_sliding_window=True, step_size=step_size, use_gaussian=True,
+        all_in_gpu=all_in_gpu, mixed_precision=mixed_precision, verbose=False, return_crop=True)
+    seg_paths, flow_paths, reg_paths, jobs = _export_flow_patient(result, trainer, output_filenames, property_list, interpolation_order,
+                                                                  force_separate_z, interpolation_order_z, save_npz, pool)
+    print("inference done. Now waiting for the segmentation export to finish...")
+    _finish_flow_patient(seg_paths, reg_paths, jobs, output_filenames, disable_postprocessing, model)
     return seg_paths, flow_paths, reg_paths
 
 
@@ -473,16 +587,36 @@ def predict_non_flow(d, trainer, output_filenames, property_list, do_tta, mixed_
     return jobs
 
 
-def predict_cases(model, list_of_lists, output_filenames, folds, save_npz, num_threads_preprocessing, num_threads_nifti_save,
-                  segs_from_prev_stage=None, do_tta=True, mixed_precision=True, overwrite_existing=False, all_in_gpu=False,
-                  step_size=0.5, checkpoint_name="model_final_checkpoint", segmentation_export_kwargs=None,
-                  disable_postprocessing=False, ed_index=0):
-    """predict.py:228-354 for ONE patient: `list_of_lists[t]` = the modality files of frame t.  All frames form the cine
-    sequence; frame `ed_index` is rotated to the front for the ED-anchored recurrence (put_ed_first, :1165-1193)."""
-    assert len(list_of_lists) == len(output_filenames)
-    if segs_from_prev_stage is not None:
-        assert len(segs_from_prev_stage) == len(output_filenames)
-    trainer, params = load_model_and_checkpoint_files(model, folds, mixed_precision=mixed_precision, checkpoint_name=checkpoint_name)
+_MODEL_CACHE = {}
+
+
+def _cached_model(model, folds, mixed_precision, checkpoint_name):
+    """load_model_and_checkpoint_files + load_checkpoint_ram once per (folder, folds, checkpoint, file time): predict_from_folder used to
+    rebuild both networks and re-read the checkpoint for every patient"""
+    key = (os.path.abspath(model), str(folds), checkpoint_name, torch.cuda.current_device())
+    stamp = os.path.getmtime(join(model, "plans.json"))
+    hit = _MODEL_CACHE.get(key)
+    if hit is None or hit[0] != stamp:
+        _MODEL_CACHE.clear()                                                     # one model resident at a time
+        trainer, params = load_model_and_checkpoint_files(model, folds, mixed_precision=mixed_precision, checkpoint_name=checkpoint_name)
+        trainer.load_checkpoint_ram(params[0], False)
+        hit = (stamp, trainer, params)
+        _MODEL_CACHE[key] = hit
+    return hit[1], hit[2]
+
+
+def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, num_threads_nifti_save, do_tta, mixed_precision, all_in_gpu,
+                      step_size, checkpoint_name, segmentation_export_kwargs, disable_postprocessing, max_slices=None):
+    """predict.py:228-354 + :1008-1110 for a LIST of patients (`cases[i]` = (list_of_lists, output_filenames, ed_index)): the model is loaded
+    once, frames are read and preprocessed by a thread pool one group of patients ahead, every group's cropped slices (up to `max_slices`)
+    share one device batch, and finished patients are exported by the NIfTI pool while the next group is on the device."""
+    import time
+    from collections import deque
+    t_start = time.perf_counter()
+    max_slices = max_slices or MAX_SLICES_PER_LAUNCH
+    trainer, params = _cached_model(model, folds, mixed_precision, checkpoint_name)
+    timing = {"load_s": time.perf_counter() - t_start, "preprocess_wait_s": 0.0, "preprocess_work_s": 0.0, "device_s": 0.0, "export_wait_s": 0.0,
+              "export_work_s": 0.0, "device_batches": 0, "patients": len(cases), "frames": 0, "slices": 0}
     if segmentation_export_kwargs is None:                                       # predict.py:286-296
         exp = trainer.plans.get("segmentation_export_params") or {}
         force_separate_z = exp.get("force_separate_z")
@@ -492,23 +626,101 @@ def predict_cases(model, list_of_lists, output_filenames, folds, save_npz, num_t
         force_separate_z = segmentation_export_kwargs["force_separate_z"]
         interpolation_order = segmentation_export_kwargs["interpolation_order"]
         interpolation_order_z = segmentation_export_kwargs["interpolation_order_z"]
-    trainer.load_checkpoint_ram(params[0], False)
-    for o in output_filenames:
-        for sub in ("Segmentation", "Flow", "Registered"):
-            os.makedirs(join(os.path.dirname(o), sub), exist_ok=True)
-    T = len(list_of_lists)
-    order = list(range(ed_index, T)) + list(range(0, ed_index))                 # ED first
-    pre = [trainer.preprocess_patient(list_of_lists[i]) for i in order]         # predict.py:302
+    orders = []
+    for list_of_lists, output_filenames, ed_index in cases:
+        assert len(list_of_lists) == len(output_filenames)
+        for o in output_filenames:
+            for sub in ("Segmentation", "Flow", "Registered"):
+                os.makedirs(join(os.path.dirname(o), sub), exist_ok=True)
+        T = len(list_of_lists)
+        orders.append(list(range(ed_index, T)) + list(range(0, ed_index)))      # ED first (put_ed_first, predict.py:1165-1193)
+
+    def pre_one(files):
+        t0 = time.perf_counter()
+        r = trainer.preprocess_patient(files)                                    # predict.py:302
+        return r, time.perf_counter() - t0
+
+    pre_pool = ThreadPool(max(1, num_threads_preprocessing))
     pool = ThreadPool(max(1, num_threads_nifti_save))
+    submitted = deque()                                                          # (case index, [async results per frame])
+    nxt = 0
+
+    def submit_more(lookahead):
+        nonlocal nxt
+        while nxt < len(cases) and len(submitted) < lookahead:
+            lol = cases[nxt][0]
+            submitted.append((nxt, [pre_pool.apply_async(pre_one, (lol[i],)) for i in orders[nxt]]))
+            nxt += 1
+
+    finishing = deque()                                                          # exports in flight: (seg_paths, reg_paths, jobs, output files)
     try:
-        predict_flow([p_[0] for p_ in pre], trainer, [output_filenames[i] for i in order], [p_[2] for p_ in pre], do_tta, mixed_precision,
-                     params, interpolation_order, force_separate_z, interpolation_order_z, all_in_gpu, step_size, save_npz,
-                     disable_postprocessing, model, pool)
+        # slices of a patient are only known after preprocessing; groups are filled greedily in patient order
+        submit_more(4)
+        carry = None
+        while submitted or carry is not None:
+            group, nslices = [], 0
+            while carry is not None or submitted:
+                if carry is None:
+                    ci, asyncs = submitted.popleft()
+                    t0 = time.perf_counter()
+                    got = [a.get() for a in asyncs]
+                    timing["preprocess_wait_s"] += time.perf_counter() - t0
+                    timing["preprocess_work_s"] += sum(g[1] for g in got)
+                    carry = (ci, [g[0] for g in got])
+                    submit_more(4)
+                z = carry[1][0][0].shape[1]
+                if group and nslices + z > max_slices:
+                    break
+                group.append(carry)
+                nslices += z
+                carry = None
+            t0 = time.perf_counter()
+            unl = [np.stack([p_[0] for p_ in pre]) + 1e-8 for _ci, pre in group]      # predict.py:1025
+            print("predicting %d patient(s), %d slices in one device batch" % (len(group), nslices))
+            results = trainer.predict_patients_flow(unl, do_mirroring=do_tta, mirror_axes=trainer.data_aug_params["mirror_axes"], return_crop=True)
+            torch.cuda.synchronize()
+            timing["device_s"] += time.perf_counter() - t0
+            timing["device_batches"] += 1
+            timing["slices"] += nslices
+            for (ci, pre), res in zip(group, results):
+                outs = [cases[ci][1][i] for i in orders[ci]]
+                timing["frames"] += len(outs)
+                sp, _fp, rp, jobs = _export_flow_patient(res, trainer, outs, [p_[2] for p_ in pre], interpolation_order, force_separate_z,
+                                                         interpolation_order_z, save_npz, pool)
+                finishing.append((sp, rp, jobs, outs))
+            while len(finishing) > 2 * max(1, len(group)):                       # bound the host memory held by queued exports
+                t0 = time.perf_counter()
+                sp, rp, jobs, outs = finishing.popleft()
+                timing["export_work_s"] += _finish_flow_patient(sp, rp, jobs, outs, disable_postprocessing, model)
+                timing["export_wait_s"] += time.perf_counter() - t0
+        t0 = time.perf_counter()
+        while finishing:
+            sp, rp, jobs, outs = finishing.popleft()
+            timing["export_work_s"] += _finish_flow_patient(sp, rp, jobs, outs, disable_postprocessing, model)
+        timing["export_wait_s"] += time.perf_counter() - t0
     finally:
+        pre_pool.close()
         pool.close()
+        pre_pool.join()
         pool.join()
-    return [(_subfolder_path(o, "Segmentation"), _subfolder_path(o, "Flow")[:-7] + ".npz", _subfolder_path(o, "Registered"))
-            for o in output_filenames]
+    timing["total_s"] = time.perf_counter() - t_start
+    LAST_TIMING.clear()
+    LAST_TIMING.update(timing)
+    return [[(_subfolder_path(o, "Segmentation"), _subfolder_path(o, "Flow")[:-7] + ".npz", _subfolder_path(o, "Registered")) for o in c[1]]
+            for c in cases]
+
+
+def predict_cases(model, list_of_lists, output_filenames, folds, save_npz, num_threads_preprocessing, num_threads_nifti_save,
+                  segs_from_prev_stage=None, do_tta=True, mixed_precision=True, overwrite_existing=False, all_in_gpu=False,
+                  step_size=0.5, checkpoint_name="model_final_checkpoint", segmentation_export_kwargs=None,
+                  disable_postprocessing=False, ed_index=0):
+    """predict.py:228-354 for ONE patient: `list_of_lists[t]` = the modality files of frame t.  All frames form the cine
+    sequence; frame `ed_index` is rotated to the front for the ED-anchored recurrence (put_ed_first, :1165-1193)."""
+    assert len(list_of_lists) == len(output_filenames)
+    if segs_from_prev_stage is not None:
+        assert len(segs_from_prev_stage) == len(output_filenames)
+    return _predict_patients(model, [(list_of_lists, output_filenames, ed_index)], folds, save_npz, num_threads_preprocessing, num_threads_nifti_save,
+                             do_tta, mixed_precision, all_in_gpu, step_size, checkpoint_name, segmentation_export_kwargs, disable_postprocessing)[0]
 
 
 def predict_cases_fast(model, list_of_lists, output_filenames, folds, num_threads_preprocessing, num_threads_nifti_save,
@@ -546,8 +758,8 @@ def predict_from_folder(model, input_folder, output_folder, folds, save_npz, num
     if mode not in ("normal", "fast", "fastest"):
         raise ValueError("unrecognized mode. Must be normal, fast or fastest")
     patients = sorted(p for p in os.listdir(input_folder) if os.path.isdir(join(input_folder, p)))
-    results = {}
-    for patient in patients[part_id::num_parts]:
+    shard, cases = patients[part_id::num_parts], []
+    for patient in shard:
         current_input_folder = join(input_folder, patient)
         current_output_folder = join(output_folder, patient)
         for sub in ("Flow", "Registered", "Segmentation"):
@@ -561,12 +773,15 @@ def predict_from_folder(model, input_folder, output_folder, folds, save_npz, num
         csv_path = join(current_input_folder, patient + ".csv")                  # predict.py:700, :1196-1198
         if os.path.isfile(csv_path):
             ed_index = get_ed_es_indices(csv_path)[0]
-        results[patient] = predict_cases(model, list_of_lists, output_files, folds, save_npz, num_threads_preprocessing,
-                                         num_threads_nifti_save, None, tta, mixed_precision=mixed_precision,
-                                         overwrite_existing=overwrite_existing, all_in_gpu=bool(overwrite_all_in_gpu), step_size=step_size,
-                                         checkpoint_name=checkpoint_name, segmentation_export_kwargs=segmentation_export_kwargs,
-                                         disable_postprocessing=disable_postprocessing, ed_index=ed_index)
-    return results
+        cases.append((list_of_lists, output_files, ed_index))
+    seg_exp = segmentation_export_kwargs
+    if mode != "normal":
+        assert save_npz is False                                                 # predict.py:755, :771
+    if mode == "fastest":                                                        # predict.py:504-626: nearest-neighbour export
+        seg_exp = {"force_separate_z": None, "interpolation_order": 0, "interpolation_order_z": 0}
+    res = _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, num_threads_nifti_save, tta, mixed_precision,
+                            bool(overwrite_all_in_gpu), step_size, checkpoint_name, seg_exp, disable_postprocessing) if cases else []
+    return dict(zip(shard, res))
 
 
 def main(argv=None):

@@ -499,6 +499,153 @@ def test_flow_wrapper_with_cropping_network_vs_oracle(dev):
             assert np.isnan(d) or abs(d - 1.0) <= 1e-3
 
 
+def _reduced_mtl_config():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "configs.json")) as f:
+        v = json.load(f)["adversarial_acdc"]["values"]
+    return dict(v, in_encoder_dims=[1, 16, 32], out_encoder_dims=[8, 16, 32], spatial_cross_attention_num_heads=[2, 2, 4])
+
+
+@pytest.mark.gpu
+def test_flow_wrapper_with_mtl_cropping_network_vs_oracle(dev):
+    """plans['cropping_net'] = {'type': 'mtl', ...}: the Processor's cropping network is the reference's own -- MTLmodel(num_classes=2)
+    built from adversarial_acdc.yaml's values by cineflow.config.build_2d_model (voxelmorph_saver_Lib.py:340-348) -- and the per-slice
+    window comes from its masks; label maps, centroids and the flow wrapper's values against the oracle Processor around oracle/mtl.py."""
+    from cineflow import predict as P
+    from cineflow.mtl import MTLmodel
+    from cineflow.weights import seeded_state_dict, fill_module_
+    from oracle import models as OM
+    from oracle import mtl as OMTL
+    from oracle import ops as OO
+    red = dict(in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=32, bottleneck_heads=4, dim_feedforward=48)
+    plans = P.default_plans(image_size=96, crop_size=64, flow_variant="video", seg_base=8, seg_pool=3, reduced=red)
+    plans["cropping_net"] = {"type": "mtl", "config": _reduced_mtl_config(), "window_size": 8}     # 96 -> 48 -> 24: windows of 8 tile every filtered level
+    tr = P.CineTrainer(plans, dev)
+    assert isinstance(tr.crop_net, MTLmodel) and tr.crop_net.num_classes == 2 and tr.processor.cropping_network is tr.crop_net
+    sd_s = seeded_state_dict(tr.seg_net.state_shapes(), 10)
+    sd_f = seeded_state_dict({k: v for k, v in tr.flow_net.state_shapes().items() if not k.endswith("grid")}, 11)
+    ocnet = fill_module_(OMTL.MTLmodel(96, 8, 2, [1, 16, 32], [8, 16, 32], [2, 2, 2], [2, 2, 4], 8, 1), 53).eval()
+    sd_c = seeded_state_dict(tr.crop_net.state_shapes(), 53)                # name-keyed fill: the same numbers as fill_module_ gives the oracle
+    with pytest.raises(KeyError, match="crop_state_dict"):
+        tr.load_checkpoint_ram({"seg_state_dict": sd_s, "flow_state_dict": sd_f})
+    tr.load_checkpoint_ram({"seg_state_dict": sd_s, "flow_state_dict": sd_f, "crop_state_dict": sd_c})
+    ofnet = fill_module_(OM.SegFlowGaussian(image_size=64, motion_appearance=False, **red), 11)
+    osnet = fill_module_(OM.GenericUNet2D(1, 8, 4, 3), 10)
+    oproc = OM.Processor(64, 96, ocnet)
+    g = torch.Generator().manual_seed(15)
+    T, Z, Y, X = 4, 2, 96, 96
+    unl = (torch.randn(T, 1, Z, Y, X, generator=g) * 30 + 80).numpy().astype(np.float32)
+    unl[:, :, 1, :, :40] *= 0.05
+    seg, softmax, flow, reg, _raw, crop = tr.predict_preprocessed_data_return_seg_and_softmax_flow(unl, return_crop=True)
+    for z in range(Z):
+        x_in = torch.from_numpy(np.ascontiguousarray(unl[:, :, z]))
+        with torch.no_grad():
+            ocen, olab = oproc.preprocess_no_registration(x_in)
+            ologit = torch.stack([ocnet(OO.normalize_intensity(x_in[t][None]))["pred"][0] for t in range(T)])
+        dcen, dlab = tr.processor.preprocess_no_registration(x_in.to(dev))
+        sure = (ologit[:, 0] - ologit[:, 1]).abs() > 1e-3                  # random weights: the two logits tie over flat regions
+        assert float(sure.float().mean()) > 0.3
+        assert bool((dlab.cpu().long()[sure] == olab[sure]).all())
+        if bool((dlab.cpu().long() == olab).all()):
+            assert dcen.tolist() == ocen.tolist()
+        assert crop["padding_need"][:, z].tolist() == [int(v) for v in tr.processor.adjust_cropping_window([int(v) for v in dcen])["padding_need"]]
+        oseg, osm, ofl, oreg = OM.predict_2d_tiled_flow(ofnet, osnet, unl[:, :, z], None, oproc, [int(v) for v in dcen], (96, 96))
+        assert float(np.abs(softmax[:, :, z] - osm).max()) <= 5e-5
+        assert OO.mean_epe(torch.from_numpy(flow[:, :, z]), torch.from_numpy(ofl)) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_predict_from_folder_batches_slices_across_patients(dev, tmp_path):
+    """predict_from_folder fills the device batch across patients (here: at most 5 slices per launch -> groups
+    [2 + 3], [2] for three patients) and exports in the background; every file equals the one-patient-per-launch run up to the launch
+    shapes the batch size selects (flow within 1e-4 px everywhere, label maps identical except at argmax ties)."""
+    from cineflow import predict as P
+    from cineflow.models import SegFlowGaussian, Generic_UNet
+    from cineflow.nifti import read_nifti, write_nifti
+    from cineflow.weights import seeded_state_dict
+    red = dict(in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=32, bottleneck_heads=4, dim_feedforward=48)
+    plans = P.default_plans(image_size=64, crop_size=64, flow_variant="video", seg_base=8, seg_pool=3, reduced=red)
+    seg = Generic_UNet(1, 8, 4, 3)
+    flow = SegFlowGaussian(image_size=64, motion_appearance=False, **red)
+    model = str(tmp_path / "model")
+    P.save_model_folder(model, seg, flow, plans, fold=0, seg_sd=seeded_state_dict(seg.state_shapes(), 10),
+                        flow_sd=seeded_state_dict({k: v for k, v in flow.state_shapes().items() if not k.endswith("grid")}, 11))
+    inp = tmp_path / "in"
+    g = torch.Generator().manual_seed(6)
+    T, zs = 5, {"patient001": 2, "patient002": 3, "patient003": 2}
+    for pat, Z in zs.items():
+        (inp / pat).mkdir(parents=True)
+        for t in range(T):
+            vol = torch.randn(Z, 64, 60, generator=g).numpy().astype(np.float32) * 40 + 100
+            write_nifti(str(inp / pat / ("%s_frame%02d_0000.nii.gz" % (pat, t))), vol, (1.5, 1.5, 8.0), (0, 0, 0))
+    with open(str(inp / "patient003" / "patient003.csv"), "w") as f:
+        f.write("ed_index,es_index\n2,4\n")
+    old = P.MAX_SLICES_PER_LAUNCH
+    try:
+        P.MAX_SLICES_PER_LAUNCH = 5
+        res = P.predict_from_folder(model, str(inp), str(tmp_path / "batched"), [0], False, 2, 2, None, 0, 1, True)
+        tim = dict(P.LAST_TIMING)
+        P.MAX_SLICES_PER_LAUNCH = 1
+        P.predict_from_folder(model, str(inp), str(tmp_path / "single"), [0], False, 1, 1, None, 0, 1, True)
+        assert P.LAST_TIMING["device_batches"] == 3
+    finally:
+        P.MAX_SLICES_PER_LAUNCH = old
+    assert sorted(res) == sorted(zs) and tim["device_batches"] == 2 and tim["patients"] == 3 and tim["frames"] == 3 * T and tim["slices"] == 7
+    for k in ("load_s", "preprocess_wait_s", "preprocess_work_s", "device_s", "export_wait_s", "export_work_s", "total_s"):
+        assert tim[k] >= 0.0
+    for pat, Z in zs.items():
+        for t in range(T):
+            case = "%s_frame%02d" % (pat, t)
+            for sub in ("Segmentation", "Registered"):
+                a, _ = read_nifti(str(tmp_path / "batched" / pat / sub / (case + ".nii.gz")))
+                b, _ = read_nifti(str(tmp_path / "single" / pat / sub / (case + ".nii.gz")))
+                assert a.shape == b.shape == (Z, 64, 60) and float((a == b).mean()) >= 0.999, (pat, t, sub)
+            fa = np.load(str(tmp_path / "batched" / pat / "Flow" / (case + ".npz")))["flow"]
+            fb = np.load(str(tmp_path / "single" / pat / "Flow" / (case + ".npz")))["flow"]
+            assert fa.shape == (64, 60, Z, 2) and float(np.abs(fa - fb).max()) <= 1e-4, (pat, t, float(np.abs(fa - fb).max()))
+    ed = np.load(str(tmp_path / "batched" / "patient003" / "Flow" / "patient003_frame02.npz"))["flow"]
+    assert float(np.abs(ed).max()) == 0.0                                   # the csv's ED frame
+
+
+@pytest.mark.gpu
+def test_trainer_built_from_successive_config_vs_oracle(dev):
+    """plans['flow_net'] = {'config': <successive.yaml values>}: cineflow.config builds ModelWrap(model1, model2) and the trainer drives it
+    through the flow-network interface (ED -> t cumulative flow); values against the oracle's ModelWrap on the same seeded weights."""
+    import json
+    from cineflow import predict as P
+    from cineflow.inference import chunk_orders
+    from cineflow.weights import seeded_state_dict, fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "configs.json")) as f:
+        v = json.load(f)["successive"]["values"]
+    cfg = dict(v, in_encoder_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32])
+    plans = P.default_plans(image_size=64, crop_size=64, seg_base=8, seg_pool=3)
+    plans["flow_net"] = {"config": cfg}
+    tr = P.CineTrainer(plans, dev)
+    assert isinstance(tr.flow_net, P.ModelWrapFlow)
+    sd_s = seeded_state_dict(tr.seg_net.state_shapes(), 10)
+    sd_f = seeded_state_dict({k: s for k, s in tr.flow_net.state_shapes().items() if not k.endswith("grid")}, 12)
+    tr.load_checkpoint_ram({"seg_state_dict": sd_s, "flow_state_dict": sd_f})
+    ora = fill_module_(OM.ModelWrap(OM.OpticalFlowModelSuccessive(64, 1, [6, 16, 32], [8, 16, 32]), OM.OpticalFlowModelSuccessive(64, 6, [6, 16, 32], [8, 16, 32])), 12)
+    g = torch.Generator().manual_seed(16)
+    T, Z = 6, 2
+    unl = (torch.randn(T, 1, Z, 64, 64, generator=g) * 30 + 80).numpy().astype(np.float32)
+    seg, softmax, flow, reg, _raw = tr.predict_preprocessed_data_return_seg_and_softmax_flow(unl)
+    for z in range(Z):
+        x = OO.normalize_intensity(torch.from_numpy(np.ascontiguousarray(unl[:, :, z])))          # [T,1,64,64]: the slice's whole block
+        ref = torch.zeros(T, 2, 64, 64)
+        with torch.no_grad():
+            for order in chunk_orders(T):
+                if len(order) > 1:
+                    _o1, o2 = ora(x[order][:, None])
+                    cum = o2["cumulated"] if len(order) > 2 else o2["flow"][None]
+                    for j, t in enumerate(order[1:]):
+                        ref[t] = cum[j, 0]
+        assert OO.mean_epe(torch.from_numpy(flow[:, :, z]), ref) <= 1e-4
+        assert float(ref.abs().max()) > 0
+
+
 def test_nifti_qform_only_and_4d(tmp_path):
     """A header with sform_code 0 and a valid qform (scanner / ITK-written files): direction, origin and spacing come from the quaternion,
     as ITK does; a 4-D file is refused instead of silently truncated."""
