@@ -11,6 +11,9 @@ Inputs and weights are resident in HBM before the timed region; outputs stay in 
 BASELINE config 3 (RAFT: all-pairs correlation pyramid + 12 update iterations per 256x256 frame pair,
 SegFlowGaussian.py:875-969) is measured by the same command as a nested object `config3_raft` of the ONE JSON line
 (`--variant raft` makes it the headline of the line instead; `--no-raft` skips it).
+Other variants: `successive` = config 4 with its other dispatch (successive.yaml: OpticalFlowModelSuccessive x 2 in ModelWrap, d_model 512,
+8 heads); `warp` = BASELINE config 2 (VoxelMorph warp of frame pairs); `api` = the file-level API end to end (`predict_from_folder` on
+synthetic patients in a tmpfs folder: NIfTI read + preprocessing, device, NIfTI / NPZ export) with the wall-time split.
 
 Usage (driver contract):  python bench.py --gpus N --steps K --warmup W
   * N > 1 without WORLD_SIZE in the environment: this process starts N ranks of itself (RANK / LOCAL_RANK / WORLD_SIZE /
@@ -25,9 +28,11 @@ import argparse
 import ctypes
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -43,6 +48,11 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense BF16/FP16 MFMA (neve
 # what a register-operand loop of v_mfma_f32_32x32x16_f16 sustains on this pool's MI355X with non-zero operands (the clock drops from
 # 2.37 to 1.64 GHz; all-zero operands reach 2482): tools/ubench/mfma_rate.hip, profiles/r02_mfma_rate.txt.  Reported beside `peak`, never instead.
 MFMA_F16_SUSTAINED_TFLOPS = 1720.0
+# HBM bytes per launch over algorithmic bytes, from the separate PMC passes (FETCH_SIZE / WRITE_SIZE with the guide's wide-load correction):
+# the live line carries `traffic` = algorithmic x this ratio with its source, it cannot collect counters itself (gpurun refuses --pmc next to
+# tracing, and a PMC pass serialises kernels).
+PMC_TRAFFIC_RATIO = {"conv_f16s": (1.00, "profiles/r02_pmc_hbm_traffic.md (reads 1.00-1.03x, writes 1.00x algorithmic)"),
+                     "corr": (1.18, "profiles/r01_pmc_hbm_traffic.md (reads 1.28x at dilation 4, 1.02x at dilation 1, writes exact; byte-weighted 1.18x)")}
 
 
 def synthetic_cine(B, T, S, seed):
@@ -83,8 +93,12 @@ def flow_net_kwargs(variant):
 
 
 def make_nets(variant, with_seg=True):
-    from cineflow.models import SegFlowGaussian, Generic_UNet
-    nets = [SegFlowGaussian(**flow_net_kwargs(variant))]
+    from cineflow.models import SegFlowGaussian, Generic_UNet, OpticalFlowModelSuccessive, ModelWrap
+    if variant == "successive":   # successive.yaml: in [6,128,256], out [64,128,256], d_model 512, 8 heads, PatchMerging downsampling (nnMTLTrainerV2FlowSuccessive.py:490-496)
+        from cineflow.predict import ModelWrapFlow
+        nets = [ModelWrapFlow(ModelWrap(OpticalFlowModelSuccessive(256, 1), OpticalFlowModelSuccessive(256, 6)))]
+    else:
+        nets = [SegFlowGaussian(**flow_net_kwargs(variant))]
     if with_seg:
         nets.append(Generic_UNet(1, 32, 4, 6))
     return nets
@@ -98,6 +112,8 @@ def load_nets(nets, dev, seed, world, rank):
         shapes = {k: v for k, v in net.state_shapes().items() if not k.endswith("grid")}
         sd = seeded_state_dict(shapes, seed + i) if rank == 0 else None
         sd = parallel.broadcast_state_dict(sd, shapes, dev) if world > 1 else {k: v.to(dev) for k, v in sd.items()}
+        if world > 1 and parallel.LAST_BROADCAST:
+            log("rank %d: weight broadcast %d of %.1f MB took %.1f ms" % (rank, i, parallel.LAST_BROADCAST["bytes"] / 1e6, parallel.LAST_BROADCAST["seconds"] * 1e3))
         if dev.type == "cuda":
             net.load_state_dict(sd, dev)
         else:
@@ -133,7 +149,11 @@ def cpu_baseline(variant, seed, T_sample):
             dt = time.perf_counter() - t0
         return {"value": n / dt, "unit": "frame pairs/s", "cores": torch.get_num_threads(), "kind": "port",
                 "sample": "%d frame pairs of the same workload (oracle/: grid_sample warp, one-hot label warp, np.gradient Jacobian), %.1f s" % (n, dt)}
-    fnet = fill_module_(OM.SegFlowGaussian(**flow_net_kwargs(variant)), seed)
+    if variant == "successive":
+        wrap = fill_module_(OM.ModelWrap(OM.OpticalFlowModelSuccessive(256, 1), OM.OpticalFlowModelSuccessive(256, 6)), seed)
+        fnet = lambda x: {"backward_flow": (wrap(x)[1]["cumulated"] if x.shape[0] > 2 else wrap(x)[1]["flow"][None])}   # noqa: E731
+    else:
+        fnet = fill_module_(OM.SegFlowGaussian(**flow_net_kwargs(variant)), seed)
     frames = synthetic_cine(1, T_sample, 256, 1234)
     with torch.no_grad():
         if variant == "raft":
@@ -165,6 +185,7 @@ def log(msg):
 
 
 _T0 = time.perf_counter()
+RANK = int(os.environ.get("RANK", "0"))
 
 
 def host_threads():
@@ -231,13 +252,18 @@ def read_profile(h, kid):
     return ms.value, work.value, n.value
 
 
-def hbm_roofline(name, rec):
+def hbm_roofline(name, rec, pmc=None):
     ms, byts, n = rec
     if not n:
         return None
     ach = byts / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": None, "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2)}
+    r = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+         "traffic": None, "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2)}
+    if pmc in PMC_TRAFFIC_RATIO:      # bytes per launch: algorithmic x the PMC-measured ratio (a constant with its source, see PMC_TRAFFIC_RATIO)
+        ratio, src = PMC_TRAFFIC_RATIO[pmc]
+        r.update(traffic=round(byts / n * ratio), traffic_unit="HBM bytes per launch", algorithmic_bytes_per_launch=round(byts / n),
+                 traffic_over_algorithmic=ratio, traffic_source=src)
+    return r
 
 
 def conv_roofline(h, dt):
@@ -255,7 +281,9 @@ def conv_roofline(h, dt):
                 "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4),
                 "mfma_issue_frac": round(3 * ach / MFMA_F16_PEAK_TFLOPS, 4), "vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 3),
                 "sustained_mfma_peak_measured": MFMA_F16_SUSTAINED_TFLOPS, "mfma_issue_frac_of_sustained": round(3 * ach / MFMA_F16_SUSTAINED_TFLOPS, 4),
-                "traffic": None, "traffic_note": "PMC passes are separate runs: profiles/r0*_pmc_hbm_traffic.md (1.00x algorithmic)",
+                "traffic": None, "traffic_over_algorithmic": PMC_TRAFFIC_RATIO["conv_f16s"][0], "traffic_source": PMC_TRAFFIC_RATIO["conv_f16s"][1],
+                "traffic_note": "HBM bytes per launch = algorithmic bytes (inputs read once + outputs written once, per layer shape) x traffic_over_algorithmic; "
+                                "the kernel is MFMA-bound, so the live line prices flops and carries the PMC byte ratio as a constant",
                 "launches": n, "avg_launch_us": round(ms * 1e3 / n, 2), "share_of_step_time": round(ms * 1e-3 / dt, 3)}
     return {"bound": "mfma", "kernel": "conv_igemm_f32_kernel<%d,2>" % (1, 2, 4)[dom], "achieved": round(ach, 3),
             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
@@ -269,18 +297,20 @@ def timed(fn, steps, warmup, h, dev, what):
         fn()
         torch.cuda.synchronize()
         log("%s: warm-up step done" % what)
-    _lib.check(h.cf_profile_enable(60000), "cf_profile_enable")
+    if RANK == 0:      # per-launch event pairs (the roofline's source) on rank 0 only: the other ranks of an N-GPU run just do the work
+        _lib.check(h.cf_profile_enable(60000), "cf_profile_enable")
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = fn()
     torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
     parallel.barrier()
     dt = time.perf_counter() - t0
     del out
     dt = parallel.max_over_ranks(dt, dev)
-    log("%s: %d steps in %.3f s" % (what, steps, dt))
+    log("%s: rank %d: %d steps in %.3f s (max over ranks incl. barrier: %.3f s)" % (what, RANK, steps, mine, dt))
     return dt
 
 
@@ -297,7 +327,7 @@ def bench_joint(args, dev, h, world, rank):
     roofline = conv_roofline(h, dt)
     corr = [read_profile(h, k) for k in (3, 4, 5)]
     tot = tuple(sum(c[i] for c in corr) for i in range(3))
-    roofline_corr = hbm_roofline("corr_volume_p7_kernel<1|2|4> (persistent)", tot)
+    roofline_corr = hbm_roofline("corr_volume_p7_kernel<1|2|4> (persistent)", tot, pmc="corr")
     if roofline_corr:
         roofline_corr["per_level"] = {"s%d" % s: {"GB/s": round(c[1] / (c[0] * 1e-3) / 1e9, 1), "avg_launch_us": round(c[0] * 1e3 / c[2], 2)}
                                       for s, c in zip((1, 2, 4), corr) if c[2]}
@@ -309,7 +339,9 @@ def bench_joint(args, dev, h, world, rank):
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 MFMA hi/lo split, f32 accumulate (f32-class)" if args.conv_mode == "f16s" else "f32", "data": "synthetic",
         "config": {"workload": "BASELINE config 4: joint seg+flow over 256x256x%d cine slices; Generic_UNet(32 base, 6 pools) 4-flip TTA on "
-                               "every frame + SegFlowGaussian(%s.yaml) two-chunk ED-anchored recurrence + fused label warp" % (T, args.variant),
+                               "every frame + %s two-chunk ED-anchored recurrence + fused label warp"
+                               % (T, "ModelWrap(OpticalFlowModelSuccessive x 2, successive.yaml: d_model 512, 8 heads)" if args.variant == "successive"
+                                  else "SegFlowGaussian(%s.yaml)" % args.variant),
                    "slices_per_step_per_gpu": B, "frames_per_slice": T, "image": "256x256", "sharding": "patients, rank = part_id"},
         "roofline": roofline, "roofline_corr": roofline_corr,
     }
@@ -356,7 +388,7 @@ def synthetic_pairs(B, S, seed):
 
 
 def bench_warp(args, dev, h, world, rank, steps, warmup):
-    """BASELINE config 1: the VoxelMorph warp of 256x256 frame pairs as voxelmorph_saver_* / compute_jacobian use it; a step = B pairs:
+    """BASELINE config 2: the VoxelMorph warp of 256x256 frame pairs as voxelmorph_saver_* / compute_jacobian use it; a step = B pairs:
     SpatialTransformer on the moving image, warp_linear label propagation (one-hot -> warp -> argmax), Jacobian determinant"""
     from cineflow import ops
     B, S = args.pairs, 256
@@ -380,11 +412,87 @@ def bench_warp(args, dev, h, world, rank, steps, warmup):
         "metric": "VoxelMorph warp frame pairs/sec at 256x256", "value": round(pairs / dt, 1), "unit": "frame pairs/s", "n_gpus": world,
         "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (Jacobian f64)", "data": "synthetic",
-        "config": {"workload": "BASELINE config 1: per 256x256 frame pair, SpatialTransformer warp of the moving image, warp_linear label "
+        "config": {"workload": "BASELINE config 2: per 256x256 frame pair, SpatialTransformer warp of the moving image, warp_linear label "
                                "propagation (4 classes) and the Jacobian determinant of the displacement", "pairs_per_step_per_gpu": B,
                    "image": "256x256"},
         "roofline": roofs[dom], "roofline_other": [r for i, r in enumerate(roofs) if i != dom],
     }
+
+
+def bench_api(args, dev, world, rank):
+    """The file-level API end to end (reference predict.py:665-780 -> :228-354 -> :1008-1110): `predict_from_folder` on
+    P synthetic patients (8 slices x T frames x 256x256 each, one gzip NIfTI per frame) in a tmpfs folder: model folder read from disk,
+    NIfTI read + crop-to-nonzero + z-score, cropped slices of several patients batched per device launch, NIfTI / NPZ export in the background.
+    A step = one predict_from_folder call over all P patients; `value` = frames/s including all of that (the model itself is loaded by the
+    untimed warm-up call and stays cached, as a serving process would keep it)."""
+    from cineflow import predict as P
+    from cineflow import parallel
+    from cineflow.nifti import write_nifti
+    from cineflow.weights import seeded_state_dict
+    npat, Z, T, S = args.patients, 8, args.frames, 256
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    root = tempfile.mkdtemp(prefix="cineflow_api_r%d_" % rank, dir=base)
+    try:
+        t0 = time.perf_counter()
+        fnet, snet = make_nets("video")
+        plans = P.default_plans(image_size=S, crop_size=S, flow_variant="video", seg_base=32, seg_pool=6)
+        model = os.path.join(root, "model")
+        P.save_model_folder(model, snet, fnet, plans, fold=0, seg_sd=seeded_state_dict(snet.state_shapes(), 1235),
+                            flow_sd=seeded_state_dict({k: v for k, v in fnet.state_shapes().items() if not k.endswith("grid")}, 1234))
+        del fnet, snet
+        inp = os.path.join(root, "in")
+        for p in range(npat):
+            frames = synthetic_cine(Z, T, S, 1234 + rank * npat + p)[:, :, 0].numpy() * 60.0 + 200.0      # [T,Z,S,S], scanner-like intensities
+            pat = "patient%03d" % p
+            os.makedirs(os.path.join(inp, pat))
+            for t in range(T):
+                write_nifti(os.path.join(inp, pat, "%s_frame%02d_0000.nii.gz" % (pat, t)), frames[t].astype(np.float32), (1.25, 1.25, 10.0), (0.0, 0.0, 0.0))
+        log("api: model folder + %d patients x %d frames written to %s in %.1f s" % (npat, T, root, time.perf_counter() - t0))
+        threads = host_threads()
+
+        def call(tag, n):
+            out = os.path.join(root, "out_" + tag)
+            sub = os.path.join(root, "in_" + tag)
+            os.makedirs(sub)
+            for p in range(n):
+                os.symlink(os.path.join(inp, "patient%03d" % p), os.path.join(sub, "patient%03d" % p))
+            P.predict_from_folder(model, sub, out, [0], False, threads, threads, None, 0, 1, True, disable_postprocessing=True)
+            tim = dict(P.LAST_TIMING)
+            shutil.rmtree(out)
+            return tim
+
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):            # the API prints per-patient progress like the reference; keep stdout for the JSON line
+            for w in range(max(1, args.warmup)):
+                tim = call("warm%d" % w, min(2, npat))                 # loads the model folder (cached afterwards), warms allocator and kernels
+                log("api: warm-up call done (model load %.1f s)" % tim["load_s"])
+            load_s = tim["load_s"]
+            parallel.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            tims = [call("step%d" % k, npat) for k in range(args.steps)]
+            torch.cuda.synchronize()
+            parallel.barrier()
+            dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+        split = {k: round(sum(t[k] for t in tims) / args.steps, 3) for k in ("preprocess_wait_s", "preprocess_work_s", "device_s", "export_wait_s", "export_work_s", "total_s")}
+        split["device_batches_per_step"] = tims[0]["device_batches"]
+        split["model_load_s_cold"] = round(load_s, 3)
+        frames_total = world * npat * Z * T * args.steps
+        return {
+            "metric": "cine frames/sec (seg+flow) at 256x256, predict_from_folder end to end", "value": round(frames_total / dt, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16 MFMA hi/lo split, f32 accumulate (f32-class)", "data": "synthetic",
+            "config": {"workload": "predict_from_folder (nnunet/inference/predict.py:665-780 API) on %d synthetic patients x %d slices x %d frames x 256x256 "
+                                   "from gzip NIfTI files in tmpfs: read + preprocess, Generic_UNet 4-flip TTA + SegFlowGaussian(video.yaml) + label warp with "
+                                   "up to %d slices of several patients per device batch, NIfTI / NPZ export; host work INSIDE the timed region" % (npat, Z, T, P.MAX_SLICES_PER_LAUNCH),
+                       "patients_per_step_per_gpu": npat, "slices_per_patient": Z, "frames_per_slice": T, "host_threads": threads},
+            "wall_time_split_per_step": split,
+            "note": "preprocess_wait / device / export_wait are what the calling thread spent blocked in each stage (they add up to total); *_work are summed "
+                    "thread times of the background pools; the device-only rate of the same networks is the default variant's `value`",
+        }
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def dry_run(args, world, rank):
@@ -392,7 +500,8 @@ def dry_run(args, world, rank):
     the measured path; the GPU step is a sleep.  No libcineflow_hip.so call (there is no GPU to make one on)."""
     from cineflow import parallel
     dev = torch.device("cpu")
-    nets = [] if args.variant == "warp" else load_nets(make_nets(args.variant, with_seg=args.variant != "raft"), dev, 1234, world, rank)
+    variant = "video" if args.variant == "api" else args.variant
+    nets = [] if variant == "warp" else load_nets(make_nets(variant, with_seg=variant != "raft"), dev, 1234, world, rank)
     sums = [n._dry_checksum for n in nets]
     frames = synthetic_cine(2, 4, 64, 1234 + rank)
     parallel.barrier()
@@ -416,12 +525,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--slices", type=int, default=64, help="cine slices per step and per GPU (B); 32 -> 48 -> 64 measured 707.8 -> 713.0 -> 717.4 frames/s on one box")
+    ap.add_argument("--slices", type=int, default=None, help="cine slices per step and per GPU (B); 32 -> 48 -> 64 measured 707.8 -> 713.0 -> 717.4 frames/s on one box")
     ap.add_argument("--frames", type=int, default=30, help="frames per cine slice (T)")
     ap.add_argument("--pairs", type=int, default=None, help="frame pairs per step and per GPU (default: 128 for raft, 960 for warp)")
-    ap.add_argument("--variant", default="video", choices=["video", "raft_config", "raft", "warp"],
+    ap.add_argument("--patients", type=int, default=16, help="api variant: synthetic patients (8 slices each) per step and per GPU")
+    ap.add_argument("--variant", default="video", choices=["video", "raft_config", "successive", "raft", "warp", "api"],
                     help="video / raft_config: BASELINE config 4 with that flow dispatch; raft: BASELINE config 3 as the headline line; "
-                         "warp: BASELINE config 1 (VoxelMorph warp of frame pairs)")
+                         "warp: BASELINE config 2 (VoxelMorph warp of frame pairs); successive: config 4 with the successive.yaml pair of networks; "
+                         "api: predict_from_folder end to end on synthetic patients")
     ap.add_argument("--no-raft", action="store_true", help="skip the nested BASELINE config 3 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", default="f16s", choices=["f16s", "f32"], help="f16s: f16-MFMA hi/lo split (default); f32: exact fp32 MFMA")
@@ -430,6 +541,10 @@ def main():
     args = ap.parse_args()
     if args.pairs is None:
         args.pairs = 960 if args.variant == "warp" else 128      # RAFT: 64 / 128 / 256 pairs per step measured 995 / 1033 / 1036 pairs/s
+    if args.slices is None:
+        # successive.yaml's model1 takes every frame of a half sequence through its encoder as ONE batch (T x B images): 16 slices already
+        # give 256-image launches
+        args.slices = 16 if args.variant == "successive" else 64
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))           # before any GPU call in this process
@@ -457,9 +572,12 @@ def main():
         line = bench_raft(args, dev, h, world, rank, args.steps, args.warmup)
     elif args.variant == "warp":
         line = bench_warp(args, dev, h, world, rank, args.steps, args.warmup)
+    elif args.variant == "api":
+        line = bench_api(args, dev, world, rank)
+        args.no_cpu_baseline = True       # the CPU path of this metric is the default variant's cpu_baseline (the oracle has no file-level API)
     else:
         line = bench_joint(args, dev, h, world, rank)
-        if not args.no_raft:
+        if not args.no_raft and args.variant != "successive":
             torch.cuda.empty_cache()
             line["config3_raft"] = bench_raft(args, dev, h, world, rank, max(1, args.steps), 1)
     if rank == 0:

@@ -56,6 +56,7 @@ SIGNATURES = {
     "cf_gru_reset_mul": [P, P, P, I, I, I, P],
     "cf_gru_blend": [P, P, P, P, I, I, I, P],
     "cf_binary": [I, P, P, P, L, L, P],
+    "cf_count_out_of_range": [P, L, F, P, P],
     "cf_copy_channels": [P, I, I, P, I, I, I, I, I, I, P],
     "cf_coords_grid": [P, I, I, I, P],
     "cf_crop2d": [P, P, I, I, I, I, I, I, I, P],

@@ -462,8 +462,8 @@ class StackedConvLayers(Module):
                 kw = {} if (x2 is None or i > 0) else {"x2": x2}
                 y, ws_b = b.conv(x, stats_groups=b.instnorm.groups, **kw)
             nxt = defer_last if last else self.blocks[i + 1].conv
-            if (nxt is not None and ws_b is not None and nxt.ks == (3, 3) and nxt.stride == 1 and getattr(nxt, "_f16s", False)
-                    and ops.prenorm_ok(y, nxt.cout)):
+            if (nxt is not None and ws_b is not None and nxt.ks == (3, 3) and nxt.stride == 1 and getattr(nxt, "sub", None) is None
+                    and getattr(nxt, "_f16s", False) and ops.prenorm_ok(y, nxt.cout)):
                 pending = (y, ws_b, b.instnorm)
                 continue
             if last and nxt is not None and ws_b is not None and nxt.ks == (1, 1) and nxt.stride == 1 and ops.norm_head_ok(y, nxt.cout):
@@ -484,24 +484,29 @@ class Generic_UNet(Module):
 
     MAX_FILTERS_2D = 480
 
-    def __init__(self, input_channels, base_num_features, num_classes, num_pool, num_conv_per_stage=2):
+    def __init__(self, input_channels, base_num_features, num_classes, num_pool, num_conv_per_stage=2, pool_op_kernel_sizes=None):
+        """pool_op_kernel_sizes: the plans' per-stage pooling kernels (generic_UNet.py:247-248; strided first convolutions :283-285,
+        transposed convolutions :343-344), e.g. [[2,2]]*5 + [[2,1]] for the ACDC 2-D patch (256, 224); default (2, 2) everywhere."""
         super().__init__()
         self.num_classes = num_classes
         self.input_channels = input_channels
+        pool = [tuple(int(v) for v in p_) for p_ in (pool_op_kernel_sizes or [(2, 2)] * num_pool)]
+        assert len(pool) == num_pool and all(p_ in ((2, 2), (2, 1), (1, 2)) for p_ in pool), "pooling kernels (2,2), (2,1) or (1,2), one per stage"
+        self.pool_op_kernel_sizes = pool
         ctx, loc, tu, seg = [], [], [], []
         out_f, in_f = base_num_features, input_channels
         for d in range(num_pool):
-            ctx.append(StackedConvLayers(in_f, out_f, num_conv_per_stage, 2 if d != 0 else None))
+            ctx.append(StackedConvLayers(in_f, out_f, num_conv_per_stage, pool[d - 1] if d != 0 else None))
             in_f = out_f
             out_f = min(int(np.round(out_f * 2)), self.MAX_FILTERS_2D)
         final = out_f
-        ctx.append({0: StackedConvLayers(in_f, out_f, num_conv_per_stage - 1, 2), 1: StackedConvLayers(out_f, final, 1)})
+        ctx.append({0: StackedConvLayers(in_f, out_f, num_conv_per_stage - 1, pool[-1]), 1: StackedConvLayers(out_f, final, 1)})
         skip_ch = [c.output_channels for c in ctx[:-1]]
         for u in range(num_pool):
             from_down = final
             from_skip = skip_ch[-(1 + u)]
             final = from_skip
-            tu.append(ConvTranspose2d(from_down, from_skip, bias=False))
+            tu.append(ConvTranspose2d(from_down, from_skip, bias=False, kernel_size=pool[-(u + 1)]))
             loc.append({0: StackedConvLayers(from_skip * 2, from_skip, num_conv_per_stage - 1), 1: StackedConvLayers(from_skip, final, 1)})
             seg.append(Conv2d(final, num_classes, 1, bias=False))
         self.conv_blocks_localization = loc

@@ -81,6 +81,16 @@ class Conv2d(Module):
         super().__init__()
         ks = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
         pd = (padding, padding) if isinstance(padding, int) else tuple(padding)
+        # per-axis strides (the plans' anisotropic pooling stages, e.g. (2, 1) at the bottom of the ACDC 2-D U-Net): the kernels take one
+        # stride for both axes, so an unequal pair runs at stride 1 and the output is subsampled -- those stages are a few pixels wide
+        self.sub = None
+        if not isinstance(stride, int):
+            sy, sx = (int(v) for v in stride)
+            if sy == sx:
+                stride = sy
+            else:
+                assert ks[0] % 2 == 1 and ks[1] % 2 == 1 and pd == (ks[0] // 2, ks[1] // 2), "per-axis strides are built for 'same' padded kernels"
+                self.sub, stride = (sy, sx), 1
         self.cin, self.cout, self.ks, self.stride, self.pad = cin, cout, ks, stride, pd
         self._param("weight", (cout, cin, ks[0], ks[1]))
         if bias:
@@ -105,6 +115,14 @@ class Conv2d(Module):
 
     def forward(self, x, x2=None, act=None, res=None, out=None, out_coff=0, stats_groups=None):
         """stats_groups=G: returns (out, ws) with the GroupNorm statistics of `out` when the f16 kernel can fuse them, else (out, None)."""
+        if self.sub is not None:
+            assert act is None and res is None and out is None, "per-axis strides: plain convolution only"
+            y = self.forward_plain(x, x2)
+            y = y[:, :, ::self.sub[0], ::self.sub[1]].contiguous()
+            return (y, None) if stats_groups else y
+        return self.forward_plain(x, x2, act, res, out, out_coff, stats_groups)
+
+    def forward_plain(self, x, x2=None, act=None, res=None, out=None, out_coff=0, stats_groups=None):
         if (x2 is None and act is None and res is None and out is None and ops.CONV_MODE == "f16s"
                 and ops.small_cin_supported(self.cin, self.ks[0], self.ks[1], self.stride, self.pad, stats_groups)):
             return ops.conv2d_small_cin(x, self._p["weight"], self._p.get("bias"), stats_groups)      # the stems: direct fp32, HBM-bound
@@ -123,21 +141,41 @@ class Conv2d(Module):
 
 
 class ConvTranspose2d(Module):
-    """nn.ConvTranspose2d(kernel_size=2, stride=2)."""
+    """nn.ConvTranspose2d(kernel_size = stride = (2, 2)); (2, 1) / (1, 2) for the plans' anisotropic stages (generic_UNet.py:343-344): a 1x1
+    convolution to Cout * k rows of the GEMM whose outputs are interleaved along the up-sampled axis by a strided copy (bottom-of-the-net
+    maps of a few pixels)."""
 
-    def __init__(self, cin, cout, bias=True):
+    def __init__(self, cin, cout, bias=True, kernel_size=(2, 2)):
         super().__init__()
-        self.cin, self.cout = cin, cout
-        self._param("weight", (cin, cout, 2, 2))
+        self.cin, self.cout, self.ks = cin, cout, tuple(int(v) for v in kernel_size)
+        assert self.ks in ((2, 2), (2, 1), (1, 2)), "transposed kernel (2,2), (2,1) or (1,2)"
+        self._param("weight", (cin, cout) + self.ks)
         if bias:
             self._param("bias", (cout,))
 
     def _prepare(self):
         if "weight" in self._p:
-            w = self._p["weight"]  # [Cin,Cout,2,2] -> GEMM rows m = co*4 + dy*2 + dx
-            self._wpk, self._ws = ops.pack_conv_weight_f16s(w.permute(1, 2, 3, 0).reshape(self.cout * 4, self.cin, 1, 1))
+            w = self._p["weight"]  # [Cin,Cout,kh,kw] -> GEMM rows m = co*kh*kw + dy*kw + dx
+            if self.ks == (2, 2):
+                self._wpk, self._ws = ops.pack_conv_weight_f16s(w.permute(1, 2, 3, 0).reshape(self.cout * 4, self.cin, 1, 1))
+            else:
+                k = self.ks[0] * self.ks[1]
+                self._w1 = Conv2d(self.cin, self.cout * k, 1, bias="bias" in self._p)     # (leading underscore: not a state-dict child)
+                self._w1._p["weight"] = w.permute(1, 2, 3, 0).reshape(self.cout * k, self.cin, 1, 1).contiguous()
+                if "bias" in self._p:
+                    self._w1._p["bias"] = self._p["bias"].repeat_interleave(k).contiguous()
+                self._w1._prepare()
+
+    def _forward_aniso(self, x):
+        B, _, H, W = x.shape
+        y = self._w1(x).view(B, self.cout, self.ks[0], self.ks[1], H, W)
+        return y.permute(0, 1, 4, 2, 5, 3).reshape(B, self.cout, H * self.ks[0], W * self.ks[1]).contiguous()
 
     def forward(self, x, out=None, out_coff=0, stats_groups=None):
+        if self.ks != (2, 2):
+            assert out is None, "anisotropic transposed convolution writes its own tensor"
+            y = self._forward_aniso(x)
+            return (y, None) if stats_groups else y
         if ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, None, 1, out_sample_elems=(self.cout if out is None else out.shape[1]) * 4 * x.shape[2] * x.shape[3],
                                                            out_hw=x.shape[2] * x.shape[3]):
             return ops.conv_transpose2d_k2s2_f16s(x, self._wpk, self._ws, self._p.get("bias"), self.cout, out=out, out_coff=out_coff,

@@ -221,6 +221,32 @@ def pack_conv_weight_f16s(w, c1=None):
     return x.view(-1), s
 
 
+# CF_F16S_RANGE_CHECK=1 (debug): every input of an f16-split convolution is scanned for values the hi/lo split cannot carry (non-finite or
+# |x| >= 65504, e.g. a `noNorm` modality fed to a network without an input normalisation); f16s_range_violations() returns the count so far.
+# Such values come out of the kernel as NaN by design; the exact route for them is set_conv_mode("f32").
+F16S_RANGE_CHECK = os.environ.get("CF_F16S_RANGE_CHECK", "0") == "1"
+_range_counter = {}
+
+
+def _range_check(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        c = _range_counter.get(t.device)
+        if c is None:
+            c = _range_counter[t.device] = torch.zeros(1, dtype=torch.int64, device=t.device)
+        check(lib().cf_count_out_of_range(_f32(t), t.numel(), 65504.0, c.data_ptr(), _stream()), "cf_count_out_of_range")
+
+
+def f16s_range_violations(reset=False):
+    """number of f16-split convolution input elements seen outside the supported range since the last reset (0 unless F16S_RANGE_CHECK)"""
+    n = sum(int(c.item()) for c in _range_counter.values())
+    if reset:
+        for c in _range_counter.values():
+            c.zero_()
+    return n
+
+
 _zero_pool = {}
 
 
@@ -251,6 +277,8 @@ def conv2d_f16s(x1, wpk, wscale, bias, cout, kh, kw, stride=1, pad=(0, 0), x2=No
     if res is not None:
         assert res.shape == (B, cout, Ho, Wo)
     assert wpk.dtype == torch.float16 and wpk.is_cuda
+    if F16S_RANGE_CHECK:
+        _range_check(x1, x2)
     ws = _zeroed_stats_ws(2 * B * stats_groups, x1.device) if stats_groups else None
     check(lib().cf_conv2d_f16s(_f32(x1), C1, _opt(x2), C2, wpk.data_ptr(), _opt(bias), _opt(res), _f32(out), out.shape[1], out_coff, B, H, W,
                                cout, kh, kw, stride, pad[0], pad[1], ACT[act], float(alpha) * (2.0 ** -wscale),
@@ -330,6 +358,8 @@ def conv2d_f16s_prenorm(x, coef, slope, wpk, wscale, bias, cout, stats_groups=No
 
 def conv_transpose2d_k2s2_f16s(x, wpk, wscale, bias, cout, out=None, out_coff=0, stats_groups=None):
     B, Cin, H, W = x.shape
+    if F16S_RANGE_CHECK:
+        _range_check(x)
     if out is None:
         out = torch.empty((B, cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
     ws = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None

@@ -24,10 +24,18 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
         if backend == "nccl":
+            # bind this rank to ITS GPU before the process group exists and tell the group so: without device_id the first collective opens
+            # a lazy context on device 0 from every rank (memory and time lost on GPU 0 of an 8-rank job).  Every GPU stays visible to every
+            # rank -- RCCL's xGMI peer paths need that -- so no *_VISIBLE_DEVICES masking here.
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local_rank
+
+
+LAST_BROADCAST = {}      # {'seconds', 'bytes'} of the last flat weight broadcast on this rank (bench.py reports it on stderr)
 
 
 def shard(items, part_id, num_parts):
@@ -56,7 +64,12 @@ def broadcast_state_dict(sd, shapes, device, src=0):
             flat[off:off + s].copy_(sd[n].reshape(-1).to(torch.float32))
             off += s
     if world > 1:
+        import time
+        t0 = time.perf_counter()
         dist.broadcast(flat, src=src)
+        if flat.is_cuda:
+            torch.cuda.synchronize(flat.device)
+        LAST_BROADCAST.update(seconds=time.perf_counter() - t0, bytes=total * 4)
     out, off = {}, 0
     for n, s in zip(names, sizes):
         out[n] = flat[off:off + s].view(shapes[n])

@@ -125,7 +125,8 @@ class CineTrainer:
                 self.crop_net = Generic_UNet(1, ck["base_num_features"], 2, ck["num_pool"])
                 self.processor.cropping_network = CroppingNet(self.crop_net)
         sk = plans["seg_net"]
-        self.seg_net = Generic_UNet(plans["num_modalities"], sk["base_num_features"], self.num_classes, sk["num_pool"])
+        self.seg_net = Generic_UNet(plans["num_modalities"], sk["base_num_features"], self.num_classes, sk["num_pool"],
+                                    pool_op_kernel_sizes=sk.get("pool_op_kernel_sizes"))     # the plans' per-stage pooling (plans_per_stage[...]['pool_op_kernel_sizes'])
         fk = plans["flow_net"]
         if fk.get("config") is not None:
             from . import config as C

@@ -35,6 +35,17 @@ __global__ void __launch_bounds__(256) binary_kernel(int op, const float* __rest
     }
 }
 
+// debug aid of the f16-split convolutions (CF_F16S_RANGE_CHECK=1): elements that the hi/lo split cannot represent -- non-finite, or
+// |x| >= limit (65504 = fp16 max) -- are counted into one device counter; one ballot + one atomic per wave that saw any
+__global__ void __launch_bounds__(256) count_out_of_range_kernel(const float* __restrict__ x, long n, float limit, unsigned long long* __restrict__ counter) {
+    GRID_STRIDE(i, n) {
+        const float v = x[i];
+        const bool bad = !(fabsf(v) < limit);            // NaN compares false: counted
+        const unsigned long long m = __ballot(bad);
+        if (m && (threadIdx.x & 63) == (unsigned)__ffsll((long long)m) - 1u) atomicAdd(counter, (unsigned long long)__popcll(m));
+    }
+}
+
 __global__ void __launch_bounds__(256) copy_channels_kernel(const float* __restrict__ src, int sct, int sco, float* __restrict__ dst,
                                                            int dct, int dco, int C, int HW, int act, long total) {
     GRID_STRIDE(i, total) {
@@ -228,6 +239,11 @@ extern "C" int cf_binary(int op, const float* a, const float* b, float* out, lon
     CF_REQUIRE(a && b && out, "null pointer");
     CF_REQUIRE(n > 0 && b_period > 0 && b_period <= n && op >= CF_OP_ADD && op <= CF_OP_MUL, "bad arguments");
     LAUNCH_FLAT(binary_kernel, n, op, a, b, out, n, b_period);
+}
+
+extern "C" int cf_count_out_of_range(const float* x, long n, float limit, unsigned long long* counter, void* stream) {
+    CF_REQUIRE(x && counter && n > 0 && limit > 0.f, "bad arguments");
+    LAUNCH_FLAT(count_out_of_range_kernel, n, x, n, limit, counter);
 }
 
 extern "C" int cf_copy_channels(const float* src, int src_ctotal, int src_coff, float* dst, int dst_ctotal, int dst_coff, int B,

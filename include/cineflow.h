@@ -121,8 +121,8 @@ int cf_conv2d(const float* x1, int C1, const float* x2, int C2, const float* wt,
  * Sizes: the kernel addresses its inputs with 32-bit offsets; ONE SAMPLE of x1 / x2 must stay below 2 GiB, a batch of any
  * size is cut into sub-batches inside the library (same kernel, same numbers).
  * Activation range: |x| < 65504 (fp16's range for the hi half).  Larger magnitudes, Inf and NaN are not clamped: they come
- * out as NaN, as loudly as in an fp32 convolution fed with NaN -- and, when Cin is not a multiple of the chunk size, the channel tail of
- * sample b is read from the first channels of sample b + 1 (against zero weights), so a NaN there also poisons sample b.  Below 2^-14 |x| the lo half goes subnormal (absolute error
+ * out as NaN, as loudly as in an fp32 convolution fed with NaN, and stay inside their own sample (the zero-weight channel tail of a chunk
+ * is never fetched, so nothing of sample b + 1 reaches sample b).  cf_count_out_of_range is the debug check.  Below 2^-14 |x| the lo half goes subnormal (absolute error
  * 2^-25), which is under the fp32 rounding of the sum for the normalised activations this path is built for.
  * gn_ws (nullable, 2*B*gn_groups doubles): on return it holds the GroupNorm / InstanceNorm statistics (sum, sum of squares
  * per (sample, group)) of the OUTPUT, accumulated in the conv epilogue (or by a statistics pass when a workgroup spans
@@ -204,6 +204,11 @@ int cf_gru_blend(const float* gates, const float* h, const float* cand, float* o
 #define CF_OP_MUL 2
 /* out[i] = a[i] op b[i % b_period]  (b_period = n for no broadcast) */
 int cf_binary(int op, const float* a, const float* b, float* out, long n, long b_period, void* stream);
+/* Debug aid for the f16-split convolutions (no reference counterpart: the reference's autocast has no range check either): *counter +=
+ * number of elements of x[0..n) that are NaN / Inf or have |x| >= limit.  cineflow.ops runs it on every cf_conv2d_f16s* input when
+ * CF_F16S_RANGE_CHECK=1 (limit 65504, the largest fp16 value) and reports through ops.f16s_range_violations(); inputs outside the range come
+ * out of those kernels as NaN (see cf_conv2d_f16s).  The exact fp32 route for such data is cf_conv2d (cineflow.ops.set_conv_mode("f32")). */
+int cf_count_out_of_range(const float* x, long n, float limit, unsigned long long* counter, void* stream);
 /* dst[b, dst_coff + c, :] = act(src[b, src_coff + c, :])  for c < C : cat / split / activation of channel slices */
 int cf_copy_channels(const float* src, int src_ctotal, int src_coff, float* dst, int dst_ctotal, int dst_coff, int B,
                      int C, int HW, int act, void* stream);

@@ -677,23 +677,27 @@ class GenericUNet2D(nn.Module):
 
     MAX_FILTERS_2D = 480
 
-    def __init__(self, input_channels, base_num_features, num_classes, num_pool, num_conv_per_stage=2):
+    def __init__(self, input_channels, base_num_features, num_classes, num_pool, num_conv_per_stage=2, pool_op_kernel_sizes=None):
+        """pool_op_kernel_sizes: per-stage pooling kernels from the plans (generic_UNet.py:247-248, first_stride :283-285, transposed
+        convolutions :343-344), e.g. [[2,2]]*5 + [[2,1]] for the ACDC 2-D patch (256, 224); default [[2,2]] * num_pool."""
         super().__init__()
         self.num_classes = num_classes
+        pool = [tuple(int(v) for v in p_) for p_ in (pool_op_kernel_sizes or [(2, 2)] * num_pool)]
+        assert len(pool) == num_pool
         ctx, loc, tu, seg = [], [], [], []
         out_f, in_f = base_num_features, input_channels
         for d in range(num_pool):
-            ctx.append(StackedConvLayers(in_f, out_f, num_conv_per_stage, 2 if d != 0 else None))
+            ctx.append(StackedConvLayers(in_f, out_f, num_conv_per_stage, pool[d - 1] if d != 0 else None))
             in_f = out_f
             out_f = min(int(np.round(out_f * 2)), self.MAX_FILTERS_2D)
         final = out_f
-        ctx.append(nn.Sequential(StackedConvLayers(in_f, out_f, num_conv_per_stage - 1, 2),
+        ctx.append(nn.Sequential(StackedConvLayers(in_f, out_f, num_conv_per_stage - 1, pool[-1]),
                                  StackedConvLayers(out_f, final, 1)))
         for u in range(num_pool):
             from_down = final
             from_skip = ctx[-(2 + u)].output_channels
             final = from_skip
-            tu.append(nn.ConvTranspose2d(from_down, from_skip, 2, 2, bias=False))
+            tu.append(nn.ConvTranspose2d(from_down, from_skip, pool[-(u + 1)], pool[-(u + 1)], bias=False))
             loc.append(nn.Sequential(StackedConvLayers(from_skip * 2, from_skip, num_conv_per_stage - 1),
                                      StackedConvLayers(from_skip, final, 1)))
         for ds in range(len(loc)):

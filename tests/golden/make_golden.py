@@ -307,6 +307,21 @@ def main():
         pin("Generic_UNet", o, ora(x), 1e-5)
         save("generic_unet", x=x, logits=o)
 
+        # a5 with the plans' anisotropic pooling (ACDC 2-D: patch (256, 224) -> pool_op_kernel_sizes [[2,2]]*5 + [[2,1]]): (2, 1) at the bottom
+        ref_a = Generic_UNet(1, 8, 4, 3, 2, 2, torch.nn.Conv2d, torch.nn.InstanceNorm2d, {"eps": 1e-5, "affine": True},
+                             torch.nn.Dropout2d, {"p": 0, "inplace": True}, torch.nn.LeakyReLU,
+                             {"negative_slope": 1e-2, "inplace": True}, True, False, lambda x: x, InitWeights_He(1e-2),
+                             [[2, 2], [2, 2], [2, 1]], [[3, 3]] * 4, False, True, True)
+        ref_a.eval()
+        ref_a.do_ds = False
+        fill_module_(ref_a, 14)
+        ora_a = OM.GenericUNet2D(1, 8, 4, 3, pool_op_kernel_sizes=[[2, 2], [2, 2], [2, 1]])
+        ora_a.load_state_dict(ref_a.state_dict(), strict=True)
+        xa = randn(2, 1, 64, 28, seed=37)                                     # 28 = 7 * 4: the bottleneck is 8 x 7
+        oa = ref_a(xa)
+        pin("Generic_UNet pool (2,2),(2,2),(2,1)", oa, ora_a(xa), 1e-5)
+        save("generic_unet_aniso", x=xa, logits=oa)
+
         # a4 TTA mirroring on that net (base-class 4-argument semantics, neural_network.py:573-621)
         ref.inference_apply_nonlin = lambda t: torch.softmax(t, 1)
         tta = SegmentationNetwork._internal_maybe_mirror_and_pred_2D(ref, x, (0, 1), True, None)

@@ -85,7 +85,7 @@ def test_bench_self_launch_propagates_rank_failure():
 
 
 def test_bench_warp_variant_inputs_and_dry_run():
-    """BASELINE config 1 variant: the synthetic frame pairs are deterministic per seed (ranks seed by rank, so shards differ), labels hold
+    """BASELINE config 2 variant: the synthetic frame pairs are deterministic per seed (ranks seed by rank, so shards differ), labels hold
     the four classes, the displacement is a few pixels and smooth; the launcher path runs for this variant too."""
     import json
     import sys
@@ -103,3 +103,26 @@ def test_bench_warp_variant_inputs_and_dry_run():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
     assert d["config"]["variant"] == "warp" and d["ranks_reporting"] == 2
+
+
+def test_bench_dry_run_eight_ranks():
+    """the driver's N = 8 launch shape rehearsed on gloo: eight fresh children, one rendezvous, the flat broadcast of the full-size weights to
+    seven receivers, barrier, MAX over eight ranks (rank 7 sleeps 80 ms per step), one JSON line"""
+    import json
+    r = _run_bench("--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "0")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_reporting"] == 8 and d["weights_identical_on_all_ranks"] is True
+    assert d["ms_per_step"] >= 80.0
+    assert sum("weight broadcast" in l for l in r.stderr.splitlines()) >= 8          # every rank reports its broadcast time on stderr
+
+
+def test_bench_successive_and_api_variants_dry_run():
+    import json
+    for variant in ("successive", "api"):
+        r = _run_bench("--gpus", "2", "--dry-run", "--variant", variant, "--steps", "1", "--warmup", "0")
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+        assert d["config"]["variant"] == variant and d["weights_identical_on_all_ranks"] is True

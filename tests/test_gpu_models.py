@@ -114,6 +114,15 @@ def test_generic_unet_and_tta(dev, golden):
     check(mirror_and_predict_2d(m, T(g["x"]).to(dev), (0, 1), True, None), g["probs"], 2e-5)
 
 
+def test_generic_unet_anisotropic_pooling(dev, golden):
+    """pool_op_kernel_sizes (2,2), (2,2), (2,1) against the reference's output: the (2,1) stage runs its strided convolution at stride 1 +
+    row subsampling and its transposed convolution as a 1x1 convolution + row interleave"""
+    from cineflow.models import Generic_UNet
+    g = golden("generic_unet_aniso")
+    m = load(Generic_UNet(1, 8, 4, 3, pool_op_kernel_sizes=[[2, 2], [2, 2], [2, 1]]), 14, dev)
+    check(m(T(g["x"]).to(dev)), g["logits"], 1e-4)
+
+
 def test_generic_unet_3d_tta_and_tiled(dev, golden):
     """3-D rows of SURVEY 8a (a3 `_internal_predict_3D_3Dconv_tiled`, a4 8-flip TTA, a5 with conv_op = Conv3d) against
     the REFERENCE's outputs: anisotropic first stage ((1,3,3) kernels, (1,2,2) pooling), then isotropic."""
@@ -284,6 +293,66 @@ def test_sliding_window_segmentation_vs_oracle(dev):
     with torch.no_grad():
         rseg, rprob = OM.predict_3d_2dconv_tiled(ora, x, (64, 48), do_mirroring=False)
     assert float(np.abs(prob - rprob).max()) <= 5e-5
+
+
+def test_baseline_config1_full_size_sliding_window_vs_oracle(dev):
+    """BASELINE config 1 at its stated size: volume [1, 10, 256, 216], patch (256, 224) -> Y padded to 224, step 0.5,
+    Gaussian weighting, 4 flips, Generic_UNet(32 base features, 6 pools, the plan's (2,1) last pooling) -- the whole 10-slice volume through
+    predict_3D_2Dconv_tiled on the device, the oracle on slices 0, 4 and 9 (CPU: ~1 s per slice)."""
+    from cineflow.models import Generic_UNet
+    from cineflow.inference import predict_3D_2Dconv_tiled, compute_steps_for_sliding_window
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    pool = [[2, 2]] * 5 + [[2, 1]]      # nnU-Net's 2-D plan for this patch: 256 = 4 * 2^6 but 224 = 7 * 2^5 -> the sixth pooling halves the rows only
+    m = load(Generic_UNet(1, 32, 4, 6, pool_op_kernel_sizes=pool), 41, dev)
+    ora = fill_module_(OM.GenericUNet2D(1, 32, 4, 6, pool_op_kernel_sizes=pool), 41)
+    x = smooth_cine(10, 1, 256, 7)[:, 0, :, :, :216].permute(1, 0, 2, 3).contiguous().numpy()        # [1, 10, 256, 216]
+    assert x.shape == (1, 10, 256, 216)
+    assert compute_steps_for_sliding_window((256, 224), (256, 224), 0.5) == [[0], [0]]                 # padded to the patch: one tile, no Gaussian (neural_network.py:657)
+    seg, prob = predict_3D_2Dconv_tiled(m, x, (256, 224), step_size=0.5, do_mirroring=True, mirror_axes=(0, 1), use_gaussian=True)
+    assert seg.shape == (10, 256, 216) and prob.shape == (4, 10, 256, 216)
+    for z in (0, 4, 9):
+        with torch.no_grad():
+            rseg, rprob = OM.predict_3d_2dconv_tiled(ora, x[:, z:z + 1], (256, 224), step_size=0.5, do_mirroring=True, mirror_axes=(0, 1), use_gaussian=True)
+        assert float(np.abs(prob[:, z] - rprob[:, 0]).max()) <= 5e-5, z
+        for k in range(4):
+            d = OO.dice(seg[z], rseg[0], k)
+            assert np.isnan(d) or abs(d - 1.0) <= 1e-3
+    # a larger field of view, so that the window really slides: [1, 2, 300, 260] -> 2 x 2 tiles of (256, 224), Gaussian importance map
+    x2 = smooth_cine(2, 1, 320, 8)[:, 0, :, :300, :260].permute(1, 0, 2, 3).contiguous().numpy()
+    seg2, prob2 = predict_3D_2Dconv_tiled(m, x2, (256, 224), step_size=0.5, do_mirroring=True, mirror_axes=(0, 1), use_gaussian=True)
+    with torch.no_grad():
+        rseg2, rprob2 = OM.predict_3d_2dconv_tiled(ora, x2[:, :1], (256, 224), step_size=0.5, do_mirroring=True, mirror_axes=(0, 1), use_gaussian=True)
+    assert float(np.abs(prob2[:, 0] - rprob2[:, 0]).max()) <= 5e-5
+    assert float((seg2[0] == rseg2[0]).mean()) >= 0.9995
+
+
+def test_model_wrap_successive_yaml_width_vs_oracle(dev):
+    """BASELINE config 4's other dispatch at its real width (successive.yaml: in [6,128,256], out [64,128,256], d_model 512, 8 heads, FFN 2048,
+    PatchMerging downsampling): ModelWrap(OpticalFlowModelSuccessive x 2), 256 x 256, T = 4 -- model1's adjacent flows and the ED -> t
+    cumulative flows after two refinement steps of model2 against the CPU oracle (2 x 12.6 M parameters, same seeded weights)."""
+    from cineflow.models import OpticalFlowModelSuccessive, ModelWrap
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    m = load(ModelWrap(OpticalFlowModelSuccessive(256, 1), OpticalFlowModelSuccessive(256, 6)), 17, dev)
+    assert m.model1.d_model == 512
+    ora = fill_module_(OM.ModelWrap(OM.OpticalFlowModelSuccessive(256, 1), OM.OpticalFlowModelSuccessive(256, 6)), 17)
+    frames = smooth_cine(4, 1, 256, 23)
+    o1, o2 = m(frames.to(dev))
+    with torch.no_grad():
+        r1, r2 = ora(frames)
+    assert o1["flow"].shape == r1["flow"].shape == (3, 1, 2, 256, 256) and o2["cumulated"].shape == r2["cumulated"].shape == (3, 1, 2, 256, 256)
+    e1 = OO.mean_epe(o1["flow"].cpu(), r1["flow"])
+    e2 = OO.mean_epe(o2["cumulated"].cpu(), r2["cumulated"])
+    assert e1 <= 1e-4 and e2 <= 1e-4, "mean EPE model1 %.3e, cumulated %.3e px (|flow| mean %.3f)" % (e1, e2, float(r2["cumulated"].abs().mean()))
+    assert float(r2["cumulated"].abs().mean()) > 1e-3
+    # the scaling-and-squaring branch of inference=True (Optical_flow_model_successive.py:399-402) at this width
+    oi = m.model1(frames[:2].to(dev), inference=True)["flow"].cpu()
+    with torch.no_grad():
+        ri = ora.model1(frames[:2], inference=True)["flow"]
+    assert OO.mean_epe(oi, ri) <= 1e-4
 
 
 def test_joint_cine_pipeline_vs_oracle(dev):

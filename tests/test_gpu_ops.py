@@ -867,3 +867,22 @@ def test_norm_head_1x1_vs_separate_passes(dev):
         two_pass = F.conv2d(applied.cpu().double(), w.cpu().double(), None if bias is None else bias.cpu().double())
         check(out, two_pass, 2e-5, "norm_head vs apply + 1x1")
     assert not ops.norm_head_ok(torch.zeros(1, 4, 3, 3, device=dev), 4) and not ops.norm_head_ok(torch.zeros(1, 4, 4, 4, device=dev), 3)
+
+
+def test_f16s_range_check_counts_unrepresentable_inputs(dev):
+    """the debug-mode counter for f16-split convolution inputs outside the supported range (|x| >= 65504, NaN, Inf)"""
+    from cineflow import ops
+    x = torch.zeros(2, 16, 8, 8)
+    x[0, 1, 2, 3], x[1, 5, 0, 0], x[1, 6, 7, 7], x[0, 0, 0, 0] = 7e4, float("nan"), float("-inf"), 65000.0     # three bad, one large but fine
+    w = torch.ones(16, 16, 3, 3) / 144
+    wpk, ws = ops.pack_conv_weight_f16s(w.to(dev))
+    old = ops.F16S_RANGE_CHECK
+    try:
+        ops.F16S_RANGE_CHECK = True
+        ops.f16s_range_violations(reset=True)
+        ops.conv2d_f16s(x.to(dev), wpk, ws, None, 16, 3, 3, 1, (1, 1))
+        assert ops.f16s_range_violations() == 3
+        ops.conv2d_f16s(torch.randn(2, 16, 8, 8).to(dev), wpk, ws, None, 16, 3, 3, 1, (1, 1))
+        assert ops.f16s_range_violations(reset=True) == 3 and ops.f16s_range_violations() == 0
+    finally:
+        ops.F16S_RANGE_CHECK = old

@@ -180,6 +180,15 @@ def test_generic_unet_and_tta(golden):
         close(OM.mirror_and_predict_2d(m, T(g["x"]), (0, 1), True, None), g["probs"], 1e-6)
 
 
+def test_generic_unet_anisotropic_pooling(golden):
+    """the plans' per-stage pooling kernels (here (2,2), (2,2), (2,1): the ACDC 2-D plan ends with (2,1) for its (256, 224) patch) against the
+    reference's Generic_UNet built with that pool_op_kernel_sizes"""
+    with torch.no_grad():
+        g = golden("generic_unet_aniso")
+        m = fill_module_(OM.GenericUNet2D(1, 8, 4, 3, pool_op_kernel_sizes=[[2, 2], [2, 2], [2, 1]]), 14)
+        close(m(T(g["x"])), g["logits"], 1e-5)
+
+
 def test_connected_component_filter(golden):
     g = golden("connected_components")
     cases = [([1, 2, 3], None), ([(1, 2), 3], None), ([1, 2], {1: 40.0, 2: 1e9}), (None, None)]

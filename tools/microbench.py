@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel micro-benchmarks on the shapes of the BASELINE workload (B = slices per step).
-Usage: python tools/microbench.py [--batch 16] [--only conv|gn|corr|attn|warp|pre|metrics|stem|raft]"""
+Usage: python tools/microbench.py [--batch 16] [--only conv|gn|corr|attn|warp|pre|metrics|stem|raft|config1]"""
 import argparse
 import math
 import os
@@ -101,6 +101,28 @@ def main():
         print("  warp_labels B%3d: %8.1f us  %6.0f GB/s" % (B, t * 1e6, B * 65536 * (8 + 1 + 1) / t / 1e9))
         t = timeit(lambda: ops.jacobian_det(flow))
         print("  jacobian B%3d: %8.1f us  %6.0f GB/s" % (B, t * 1e6, B * 65536 * (8 + 8) / t / 1e9))
+
+    if args.only in ("", "config1"):
+        # BASELINE config 1 at its stated size: one ACDC patient [1, 10, 256, 216] through the sliding-window / 4-flip TTA driver with the
+        # 32-base / 6-pool U-Net of the plan (last pooling (2, 1)): host numpy volume in, host label map + softmax out (PCIe included)
+        import time
+        import numpy as np
+        from cineflow.models import Generic_UNet
+        from cineflow.inference import predict_3D_2Dconv_tiled
+        from cineflow.weights import seeded_state_dict
+        net = Generic_UNet(1, 32, 4, 6, pool_op_kernel_sizes=[[2, 2]] * 5 + [[2, 1]])
+        net.load_state_dict(seeded_state_dict(net.state_shapes(), 41), dev)
+        vol = np.random.default_rng(1).normal(size=(1, 10, 256, 216)).astype(np.float32)
+        for tag, kw in (("host in / host out", {}), ("device resident outputs", {"return_device": True})):
+            predict_3D_2Dconv_tiled(net, vol, (256, 224), step_size=0.5, do_mirroring=True, mirror_axes=(0, 1), use_gaussian=True, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                predict_3D_2Dconv_tiled(net, vol, (256, 224), step_size=0.5, do_mirroring=True, mirror_axes=(0, 1), use_gaussian=True, **kw)
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / 5
+            print("== BASELINE config 1, volume [1,10,256,216], patch (256,224), 4 flips, Generic_UNet(32, 6 pools): %7.2f ms per patient = %6.1f slices/s (%s)"
+                  % (t * 1e3, 10 / t, tag))
 
     if args.only in ("", "pre"):
         # test-time preprocessing of one ACDC-sized case (BASELINE config 1 volume): wall time per stage, device resident, next to the

@@ -54,7 +54,7 @@ elif kind == "lookup":       # python tools/one_kernel.py lookup B
     coords = ops.coords_grid(B, 32, 32, dev) + 3 * torch.randn(B, 2, 32, 32, generator=g).to(dev)
     for _ in range(5):
         ops.corr_lookup(pyr, coords, 4, 4)
-elif kind == "warp":         # python tools/one_kernel.py warp B   (BASELINE config 1: warp + label warp + Jacobian of B 256x256 pairs)
+elif kind == "warp":         # python tools/one_kernel.py warp B   (BASELINE config 2: warp + label warp + Jacobian of B 256x256 pairs)
     sys.path.insert(0, ROOT)
     import bench
     B = int(sys.argv[2])
