@@ -75,6 +75,7 @@ SIGNATURES = {
     "cf_cc_count": [P, P, L, P],
     "cf_cc_remove": [P, P, P, L, I, DBL, DBL, P],
     "cf_conv2d_small_cin": [P, P, P, P, I, I, I, I, I, I, P, I, P],
+    "cf_conv2d_small_cout": [P, P, P, P, P, I, I, I, I, I, P],
     "cf_nonzero_mask": [P, I, L, P, P],
     "cf_fill_holes": [P, P, P, I, I, I, I, P],
     "cf_mask_bbox": [P, I, I, I, P, P],

@@ -16,8 +16,16 @@ _DTYPES = {2: np.uint8, 4: np.int16, 8: np.int32, 16: np.float32, 64: np.float64
 _CODES = {np.dtype(v): k for k, v in _DTYPES.items()}
 
 
+# zlib level of the .nii.gz files written here.  Python's gzip default (9) spent 0.42 s per 0.5 MB label map of the API bench -- the whole
+# export was compression (profiles/r03_api_split.md); ITK's NIfTI writer, which the reference goes through, compresses at a low level too.  The
+# level changes the file size only: the voxels a reader gets back are identical.
+GZIP_LEVEL = 2
+
+
 def _open(path, mode):
-    return gzip.open(path, mode) if str(path).endswith(".gz") else open(path, mode)
+    if str(path).endswith(".gz"):
+        return gzip.open(path, mode, compresslevel=GZIP_LEVEL) if "w" in mode else gzip.open(path, mode)
+    return open(path, mode)
 
 
 def write_nifti(path, array, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=(1, 0, 0, 0, 1, 0, 0, 0, 1)):

@@ -123,6 +123,9 @@ class Conv2d(Module):
         return self.forward_plain(x, x2, act, res, out, out_coff, stats_groups)
 
     def forward_plain(self, x, x2=None, act=None, res=None, out=None, out_coff=0, stats_groups=None):
+        if (x2 is None and act is None and out is None and not stats_groups and ops.CONV_MODE == "f16s"
+                and ops.small_cout_supported(self.cout, self.ks[0], self.ks[1], self.stride, self.pad)):
+            return ops.conv2d_small_cout(x, self._p["weight"], self._p.get("bias"), res)          # the flow heads: direct fp32, HBM-bound
         if (x2 is None and act is None and res is None and out is None and ops.CONV_MODE == "f16s"
                 and ops.small_cin_supported(self.cin, self.ks[0], self.ks[1], self.stride, self.pad, stats_groups)):
             return ops.conv2d_small_cin(x, self._p["weight"], self._p.get("bias"), stats_groups)      # the stems: direct fp32, HBM-bound

@@ -313,6 +313,24 @@ def conv2d_small_cin(x, weight, bias, stats_groups=None):
     return (out, ws) if stats_groups else out
 
 
+def small_cout_supported(cout, kh, kw, stride, pad):
+    """layers routed to cf_conv2d_small_cout: 3x3 / pad 1 / stride 1 with at most 4 output channels (the flow heads).  Measured at
+    128 x 64 x 256 x 256 -> 2: see DESIGN.md (the MFMA kernel fills 2 of its 32 rows: 16 TF)."""
+    return DIRECT_STEM and cout <= 4 and (kh, kw, tuple(pad)) == (3, 3, (1, 1)) and stride == 1
+
+
+def conv2d_small_cout(x, weight, bias, res=None):
+    """Direct exact-fp32 3x3 convolution to <= 4 channels: x [B,Cin,H,W], weight [Cout,Cin,3,3] (checkpoint layout) -> conv + bias (+ res)."""
+    B, Cin, H, W = x.shape
+    cout = weight.shape[0]
+    assert tuple(weight.shape) == (cout, Cin, 3, 3)
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    if res is not None:
+        assert res.shape == out.shape
+    check(lib().cf_conv2d_small_cout(_f32(x), _f32(weight), _opt(bias), _opt(res), _f32(out), B, Cin, H, W, cout, _stream()), "cf_conv2d_small_cout")
+    return out
+
+
 PRENORM = os.environ.get("CF_PRENORM", "1") != "0"        # 0: every normalisation runs as its own apply pass (A/B knob)
 
 
@@ -362,9 +380,9 @@ def conv_transpose2d_k2s2_f16s(x, wpk, wscale, bias, cout, out=None, out_coff=0,
         _range_check(x)
     if out is None:
         out = torch.empty((B, cout, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
-    ws = torch.empty(2 * B * stats_groups, dtype=torch.float64, device=x.device) if stats_groups else None
+    ws = _zeroed_stats_ws(2 * B * stats_groups, x.device) if stats_groups else None       # fused into the scatter epilogue (atomics: zero start)
     check(lib().cf_conv_transpose2d_k2s2_f16s(_f32(x), wpk.data_ptr(), _opt(bias), _f32(out), out.shape[1], out_coff, B, Cin, H, W, cout,
-                                              2.0 ** -wscale, None if ws is None else ws.data_ptr(), stats_groups or 0, _stream()),
+                                              2.0 ** -wscale, None if ws is None else ws.data_ptr(), -stats_groups if stats_groups else 0, _stream()),
           "cf_conv_transpose2d_k2s2_f16s")
     return (out, ws) if stats_groups else out
 

@@ -222,8 +222,20 @@ class CineTrainer:
         return {"frames": crop.view(T, Z, 1, cs, cs), "ed": ed, "pad_need": pad_need, "slicer": slicer, "geom": (T, Z, Y, X, Hp, Wp, y1, y2, x1, x2),
                 "processor": processor}
 
+    @staticmethod
+    def _to_host(tensors):
+        """device tensors -> numpy arrays through pinned staging buffers (torch's caching host allocator), one synchronisation for all of
+        them: the per-patient results are ~0.5 GB, pageable `.cpu()` copies were a fifth of the API's device stage"""
+        hosts = []
+        for t in tensors:
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            hosts.append(h)
+        torch.cuda.current_stream().synchronize()
+        return [h.numpy() for h in hosts]
+
     # -- :3427-3467 after the network call: per-slice uncrop, centre window, un-pad, host copies
-    def _flow_finish(self, prep, out, return_crop):
+    def _flow_finish(self, prep, out, return_crop, want_raw=True):
         T, Z, Y, X, Hp, Wp, y1, y2, x1, x2 = prep["geom"]
         processor, pad_need, slicer, frames, dev = prep["processor"], prep["pad_need"], prep["slicer"], prep["frames"], self.device
 
@@ -238,13 +250,16 @@ class CineTrainer:
         flow = place(out["flow"].permute(0, 2, 1, 3, 4).contiguous())                  # [T,2,Z,Y,X]
         reg = place(out["registered"].float())[:, None]                                # [T,1,Z,Y,X]
         seg = ops.argmax_channels(softmax.reshape(T, self.num_classes, -1).contiguous()).view(T, Z, Y, X)
-        raw = torch.cat([frames.permute(0, 2, 1, 3, 4), out["flow"].permute(0, 2, 1, 3, 4)], 1)
-        res = (seg.cpu().numpy(), softmax.cpu().numpy(), flow.cpu().numpy(), reg.cpu().numpy(), raw.cpu().numpy())
+        dev_out = [seg, softmax.contiguous(), flow.contiguous(), reg.contiguous()]
+        if want_raw:
+            dev_out.append(torch.cat([frames.permute(0, 2, 1, 3, 4), out["flow"].permute(0, 2, 1, 3, 4)], 1))
         if return_crop:
-            crop_out = {"softmax": out["softmax"].permute(0, 2, 1, 3, 4).contiguous().cpu().numpy(),
-                        "flow": out["flow"].permute(0, 2, 1, 3, 4).contiguous().cpu().numpy(), "registered": out["registered"].cpu().numpy(),
-                        "padding_need": pad_need, "size_before": [int(Y), int(X), int(Z)]}
-            return res + (crop_out,)
+            dev_out += [out["softmax"].permute(0, 2, 1, 3, 4).contiguous(), out["flow"].permute(0, 2, 1, 3, 4).contiguous(), out["registered"].contiguous()]
+        host = self._to_host(dev_out)
+        res = tuple(host[:4]) + ((host[4],) if want_raw else (None,))
+        if return_crop:
+            c = host[-3:]
+            return res + ({"softmax": c[0], "flow": c[1], "registered": c[2], "padding_need": pad_need, "size_before": [int(Y), int(X), int(Z)]},)
         return res
 
     # -- nnUNetTrainer.py:682-726 -> SegFlowGaussian.predict_3D_flow :2837, _internal_predict_2D_2Dconv_tiled_flow :3294-3533
@@ -260,7 +275,7 @@ class CineTrainer:
                                           pad_border_mode=pad_border_mode, pad_kwargs=pad_kwargs, centroids=[centroid], return_crop=return_crop)[0]
 
     def predict_patients_flow(self, unlabeled_list, targets=None, processor=None, do_mirroring=True, mirror_axes=None, pad_border_mode="constant",
-                              pad_kwargs=None, centroids=None, return_crop=False):
+                              pad_kwargs=None, centroids=None, return_crop=False, want_raw=True):
         """The one-patient call above for several patients whose cropped slices share ONE device batch: every patient is padded / cropped /
         z-scored on its own (`_flow_prepare`), the `[T, Z_p, 1, c, c]` stacks of the patients with the same frame count T are concatenated
         on the slice axis, predict_cine_slices runs once per such group, and each patient's slices go back through its own un-crop
@@ -285,7 +300,7 @@ class CineTrainer:
                 Z = preps[i]["frames"].shape[1]
                 outs[i] = {k: v[:, z0:z0 + Z] for k, v in out.items()}
                 z0 += Z
-        return [self._flow_finish(pr, o, return_crop) for pr, o in zip(preps, outs)]
+        return [self._flow_finish(pr, o, return_crop, want_raw) for pr, o in zip(preps, outs)]
 
 
 def load_model_and_checkpoint_files(folder, folds=None, mixed_precision=None, checkpoint_name="model_final_checkpoint", device=None):
@@ -497,9 +512,11 @@ def _export_flow_patient(result, trainer, output_filenames, property_list, inter
     """predict.py:1084-1110 for one patient's device results: transpose back, submit one export job per frame to the pool.
     Returns (seg_paths, flow_paths, reg_paths, jobs)."""
     voxelmorph_raw = _VOXELMORPH_RAW
-    seg, softmax, flow, registered, _raw, crop_out = result
+    seg, softmax, flow, registered, _raw = result[:5]
+    crop_out = result[5] if len(result) > 5 else None
     assert len(softmax) == len(flow) == len(registered)
     if voxelmorph_raw is not None:
+        assert crop_out is not None, "set_voxelmorph_raw was switched on after the device stage of this patient"
         from .voxelmorph_saver import write_raw
         patient = os.path.basename(os.path.dirname(os.path.abspath(output_filenames[0])))
         write_raw(voxelmorph_raw[0], voxelmorph_raw[1], patient, [os.path.basename(o)[:-7] for o in output_filenames], crop_out["softmax"],
@@ -517,14 +534,15 @@ def _export_flow_patient(result, trainer, output_filenames, property_list, inter
         flow_paths.append(flow_path[:-7] + ".npz")
         reg_paths.append(reg_path)
         npz = seg_path[:-7] + ".npz" if save_npz else None
-        jobs.append(pool.apply_async(_timed_export, (softmax[t], seg_path, property_list[t], interpolation_order, None, None, None, npz, None,
+        jobs.append(pool.apply_async(_timed_export, (trainer.device, softmax[t], seg_path, property_list[t], interpolation_order, None, None, None, npz, None,
                                                      force_separate_z, interpolation_order_z, False, flow[t], flow_paths[-1], registered[t], reg_path)))
     return seg_paths, flow_paths, reg_paths, jobs
 
 
-def _timed_export(*a):
+def _timed_export(dev, *a):
     import time
     t0 = time.perf_counter()
+    torch.cuda.set_device(dev)                                                   # per-thread state: the resampling kernels must run on the caller's GPU
     save_segmentation_nifti_from_softmax(*a)
     return time.perf_counter() - t0
 
@@ -636,9 +654,19 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
         T = len(list_of_lists)
         orders.append(list(range(ed_index, T)) + list(range(0, ed_index)))      # ED first (put_ed_first, predict.py:1165-1193)
 
+    import threading
+    tls = threading.local()
+
     def pre_one(files):
+        # every preprocessing thread issues its (small) device kernels on a HIP stream of its own: on the default stream they -- and the
+        # host read-backs between them -- queued behind the seconds-long network batch of the main thread
         t0 = time.perf_counter()
-        r = trainer.preprocess_patient(files)                                    # predict.py:302
+        if not hasattr(tls, "stream"):
+            torch.cuda.set_device(trainer.device)                                # the current device is per thread (a new thread starts on GPU 0)
+            tls.stream = torch.cuda.Stream(device=trainer.device)
+        with torch.cuda.stream(tls.stream):
+            r = trainer.preprocess_patient(files)                                # predict.py:302
+            tls.stream.synchronize()
         return r, time.perf_counter() - t0
 
     pre_pool = ThreadPool(max(1, num_threads_preprocessing))
@@ -678,7 +706,10 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
             t0 = time.perf_counter()
             unl = [np.stack([p_[0] for p_ in pre]) + 1e-8 for _ci, pre in group]      # predict.py:1025
             print("predicting %d patient(s), %d slices in one device batch" % (len(group), nslices))
-            results = trainer.predict_patients_flow(unl, do_mirroring=do_tta, mirror_axes=trainer.data_aug_params["mirror_axes"], return_crop=True)
+            # the crop-space copies only when the voxelmorph_saver tree is being written; the `raw` tensor (frames + crop-space flow) the
+            # reference returns for its trainer's plots is not consumed by the exporter
+            results = trainer.predict_patients_flow(unl, do_mirroring=do_tta, mirror_axes=trainer.data_aug_params["mirror_axes"],
+                                                    return_crop=_VOXELMORPH_RAW is not None, want_raw=False)
             torch.cuda.synchronize()
             timing["device_s"] += time.perf_counter() - t0
             timing["device_batches"] += 1

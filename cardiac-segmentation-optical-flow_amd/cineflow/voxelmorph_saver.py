@@ -162,12 +162,30 @@ def determine_postprocessing_custom(base, raw_subfolder_name="validation_raw", t
     return folder_all_classes_as_fg
 
 
-class Saver:
-    """The module-level state of voxelmorph_saver_Lib.py's __main__ (processor, plans entries) as an object."""
+def build_cropping_network(cropper_config, image_size, window_size, weights=None, device=None):
+    """voxelmorph_saver_Lib.py:340-345: `read_config(adversarial_acdc.yaml)` -> `build_2d_model(..., num_classes=2, processor=None)` ->
+    `load_state_dict(torch.load(<cropper weights>/model_final_checkpoint.model)['state_dict'], strict=True)`.  cropper_config: the YAML's
+    file name or its mapping; weights: a `.model` file holding {'state_dict': {name: tensor}} (read with torch.load(weights_only=True): a
+    tensor dict loads, a pickled trainer object is refused) or such a dict itself."""
+    from . import config as C
+    cfg = C.read_config(cropper_config, False, False) if isinstance(cropper_config, str) else cropper_config
+    net = C.build_2d_model(cfg, conv_layer=None, norm=None, log_function=None, image_size=image_size, window_size=window_size, middle=False,
+                           num_classes=2, processor=None)
+    if weights is not None:
+        sd = torch.load(weights, map_location="cpu", weights_only=True) if isinstance(weights, str) else weights
+        sd = sd["state_dict"] if "state_dict" in sd else sd
+        net.load_state_dict(sd, device or torch.device("cuda", torch.cuda.current_device()), strict=True)
+    return net
 
-    def __init__(self, plans, image_size, crop_size, device=None):
+
+class Saver:
+    """The module-level state of voxelmorph_saver_Lib.py's __main__ (processor, plans entries) as an object.  `cropping_network`: the
+    2-class MTLmodel the reference hands to its Processor (:340-348, `build_cropping_network` above); the post-processing itself only uses
+    the Processor's un-crop arithmetic, so None is allowed."""
+
+    def __init__(self, plans, image_size, crop_size, device=None, cropping_network=None):
         self.device = device or torch.device("cuda", torch.cuda.current_device())
-        self.processor = Processor(crop_size=crop_size, image_size=image_size)
+        self.processor = Processor(crop_size=crop_size, image_size=image_size, cropping_network=cropping_network)
         self.full_image_size = image_size
         if plans.get("transpose_forward") is None or plans.get("transpose_backward") is None:
             plans = dict(plans, transpose_forward=[0, 1, 2], transpose_backward=[0, 1, 2])                 # :346-352
@@ -240,7 +258,7 @@ class Saver:
         determine_postprocessing_custom(newpath_registered, "", final_subf_name="_postprocessed", debug=True)
 
 
-def run(pred_path, pkl_path, plans, image_size, crop_size, no_seg=False, device=None):
+def run(pred_path, pkl_path, plans, image_size, crop_size, no_seg=False, device=None, cropping_network=None):
     """voxelmorph_saver_Lib.py:284-394 (__main__) for the folder that holds `Raw/`: creates `Postprocessed/{Flow,Registered,Segmentation}`
     and processes every patient folder of `Raw/Registered`."""
     from glob import glob
@@ -249,7 +267,7 @@ def run(pred_path, pkl_path, plans, image_size, crop_size, no_seg=False, device=
     newpath = {k: join(output_dir, k) for k in ("Flow", "Registered", "Segmentation")}
     for p in newpath.values():
         os.makedirs(p)
-    saver = Saver(plans, image_size, crop_size, device)
+    saver = Saver(plans, image_size, crop_size, device, cropping_network)
     registered_dir = join(pred_path, "Raw", "Registered")
     patients = sorted(n for n in os.listdir(registered_dir) if os.path.isdir(join(registered_dir, n)))
     for patient_name in patients:
@@ -278,14 +296,18 @@ def main(argv=None):
     parser.add_argument("--plans", required=True, help="plans.json of the model folder")
     parser.add_argument("--image_size", type=int, default=None)
     parser.add_argument("--crop_size", type=int, default=None)
+    parser.add_argument("--cropper_config", default=None, help="adversarial_acdc.yaml of the cropping network (the reference reads it from the cwd, :340)")
+    parser.add_argument("--cropper_weights", default=None, help="<cropper_weights_folder_path>/model_final_checkpoint.model (:344)")
+    parser.add_argument("--window_size", type=int, default=None)
     a = parser.parse_args(argv)
-    sizes = {"Lib": (384, 192), "ACDC": (224, 128)}                                                          # :301-320
-    image_size, crop_size = sizes.get(a.dataset, (None, None))
-    image_size, crop_size = a.image_size or image_size, a.crop_size or crop_size
+    sizes = {"Lib": (384, 192, 8), "ACDC": (224, 128, 7)}                                                    # :301-320
+    image_size, crop_size, window_size = sizes.get(a.dataset, (None, None, None))
+    image_size, crop_size, window_size = a.image_size or image_size, a.crop_size or crop_size, a.window_size or window_size
     assert image_size and crop_size, "unknown dataset: pass --image_size and --crop_size"
     with open(a.plans) as f:
         plans = json.load(f)
-    return run(a.pred_path, a.pkl_path, plans, image_size, crop_size, a.no_seg)
+    net = build_cropping_network(a.cropper_config, image_size, window_size, a.cropper_weights) if a.cropper_config else None
+    return run(a.pred_path, a.pkl_path, plans, image_size, crop_size, a.no_seg, cropping_network=net)
 
 
 if __name__ == "__main__":

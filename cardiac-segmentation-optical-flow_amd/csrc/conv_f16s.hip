@@ -944,7 +944,9 @@ static int launch_conv_f16s_part(const ConvParams& p, const _Float16* wpk, hipSt
     bool fusable = false;
     launch_conv_f16s_impl(p, nullptr, s, &fusable);  // geometry probe only
     ConvParams q = p;
-    if (fusable && !p.scatter2x2) {
+    // (the transposed convolution's scatter qualifies too: its GEMM rows are co * 4 + dy * 2 + dx, so a group of Cout / groups output
+    // channels is a run of 4 * Cout / groups consecutive rows -- the same `co / cpg` with cpg = p.Cout / groups = 4 * Cout / groups)
+    if (fusable) {
         // the fused statistics accumulate with atomics: the workspace must start at zero (gn_prezeroed: the caller hands out slices
         // of a pool it zeroed with ONE memset -- the per-launch memsets were 1.2 % of the step)
         if (!p.gn_prezeroed &&

@@ -17,7 +17,8 @@ enum ProfileKernel {
     PK_CONVEX_UP = 9,                                        // RAFT convex upsampling; work = algorithmic bytes
     PK_GN_APPLY = 10,                                        // GroupNorm apply passes; work = algorithmic bytes
     PK_WARP = 11, PK_WARP_LABELS = 12, PK_JACOBIAN = 13,     // VoxelMorph warp family (2-D); work = algorithmic bytes
-    PK_COUNT = 14
+    PK_CONV_SMALL_COUT = 14,                                 // direct 3x3 convolution to <= 4 output channels (flow heads); work = algorithmic bytes
+    PK_COUNT = 15
 };
 
 bool profile_on();

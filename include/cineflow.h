@@ -266,6 +266,12 @@ int cf_resize3d(const float* src, float* dst, int N, int X, int Y, int Z, int X2
  * [B][gn_groups][2] = {sum, sum of squares} of the output per (sample, group), zeroed here; gn_groups <= 64 divides Cout. */
 int cf_conv2d_small_cin(const float* x, const float* weight, const float* bias, float* out, int B, int Cin, int H, int W, int Cout, int K,
                         double* gn_ws, int gn_groups, void* stream);
+/* Head convolutions (nn.Conv2d, 3x3 pad 1 stride 1, 1..4 OUTPUT channels: the flow head `final_conv` of Decoder2D,
+ * nnunet/lib/decoder_alt.py:890-892, and FlowHead.conv2 of the published RAFT update block) as a direct, exact fp32 kernel:
+ * out = conv(x) + bias (+ res): weight fp32 [Cout][Cin][3][3] (checkpoint layout), x [B][Cin][H][W], res / out dense [B][Cout][H][W];
+ * bias and res may be NULL. */
+int cf_conv2d_small_cout(const float* x, const float* weight, const float* bias, const float* res, float* out, int B, int Cin, int H, int W,
+                         int Cout, void* stream);
 
 /* ---------------------------------------------------------------- test-time preprocessing (the step before the path)
  * create_nonzero_mask, nnunet/preprocessing/cropping.py:25-32: mask[v] = any_c data[c][v] != 0 (uint8 [V]). */

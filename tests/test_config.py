@@ -111,3 +111,15 @@ def test_values_outside_the_hot_path_are_refused_by_name(fixtures):
         C.build_successive_model_wrap(dict(fixtures["successive"]["values"], no_error=True), 256)
     with pytest.raises(NotImplementedError, match="transformer_depth"):
         C.build_2d_model(dict(fixtures["adversarial_acdc"]["values"], transformer_depth=[2], num_heads=[3]), image_size=224, window_size=7, num_classes=2)
+
+
+def test_voxelmorph_saver_builds_the_reference_cropping_network(fixtures, tmp_path):
+    """voxelmorph_saver_Lib.py:340-348: the Processor of the saver carries MTLmodel(num_classes=2) built from adversarial_acdc.yaml"""
+    from cineflow import voxelmorph_saver as VS
+    from cineflow.mtl import MTLmodel
+    import torch
+    p = write_yaml(tmp_path, "adversarial_acdc", fixtures["adversarial_acdc"]["values"])
+    net = VS.build_cropping_network(p, image_size=224, window_size=7)
+    assert isinstance(net, MTLmodel) and net.num_classes == 2
+    s = VS.Saver({"transpose_forward": [0, 1, 2], "transpose_backward": [0, 1, 2]}, 224, 128, device=torch.device("cpu"), cropping_network=net)
+    assert s.processor.cropping_network is net and s.processor.crop_size == 128

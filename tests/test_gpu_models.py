@@ -224,8 +224,9 @@ def test_raft_net_reloaded_with_other_weights_matches_a_fresh_net(dev):
     load(m, 14, dev)                                             # other weights into the SAME object
     again = m(frames)["backward_flow"]
     fresh = load(SegFlowGaussian(**kw), 14, dev)(frames)["backward_flow"]
-    assert float((again - fresh).abs().max()) == 0.0
-    assert float((again - first).abs().max()) > 0.0
+    # (not bit-identical: the fused GroupNorm statistics meet in another order from run to run -- 5e-6 measured)
+    assert float((again - fresh).abs().max()) <= 1e-4
+    assert float((again - first).abs().max()) > 1e-2
 
 
 def test_full_width_blocks_vs_oracle(dev):

@@ -608,6 +608,14 @@ def test_conv_transpose_f16s(dev):
         wpk, ws = ops.pack_conv_weight_f16s(w.to(dev).permute(1, 2, 3, 0).reshape(Cout * 4, Cin, 1, 1))
         out = ops.conv_transpose2d_k2s2_f16s(x.to(dev), wpk, ws, None if b is None else b.to(dev), Cout)
         check(out, ref, 1e-5, "convT f16s")
+        # GroupNorm statistics of the scattered output from the epilogue (one sample per workgroup) or the statistics pass (small maps)
+        for groups in ((8, Cout) if Cout % 8 == 0 else (Cout,)):
+            out2, st = ops.conv_transpose2d_k2s2_f16s(x.to(dev), wpk, ws, None if b is None else b.to(dev), Cout, stats_groups=groups)
+            assert torch.equal(out2, out)
+            yo = out.cpu().double()
+            want = torch.stack([yo.view(B, groups, -1).sum(-1), (yo ** 2).view(B, groups, -1).sum(-1)], -1)
+            scale = yo.abs().view(B, groups, -1).sum(-1)[..., None] + 1.0
+            assert float(((st.cpu().view(B, groups, 2) - want).abs() / scale).max()) <= 2e-6, (B, Cin, H, W, Cout, groups)
 
 
 @pytest.mark.parametrize("act", ["relu", "lrelu", "tanh", "sigmoid"])
@@ -886,3 +894,25 @@ def test_f16s_range_check_counts_unrepresentable_inputs(dev):
         assert ops.f16s_range_violations(reset=True) == 3 and ops.f16s_range_violations() == 0
     finally:
         ops.F16S_RANGE_CHECK = old
+
+
+@pytest.mark.parametrize("B,Cin,H,W,Cout,bias,res", [(2, 64, 256, 256, 2, True, False),    # Decoder2D.final_conv at full size
+                                                      (3, 256, 32, 32, 2, True, True),      # RAFT FlowHead.conv2 with the residual input
+                                                      (1, 5, 13, 70, 4, False, False),      # ragged: partial column block, partial row block
+                                                      (2, 16, 9, 64, 1, True, True), (1, 8, 40, 130, 3, False, True)])
+def test_conv_small_cout_direct(dev, B, Cin, H, W, Cout, bias, res):
+    """cf_conv2d_small_cout: the flow heads as a direct exact-fp32 kernel (buffer-resource taps: zero padding by range check)"""
+    from cineflow import ops
+    from cineflow.nn import Conv2d
+    x = randn(B, Cin, H, W, seed=70)
+    w = randn(Cout, Cin, 3, 3, seed=71) / math.sqrt(9 * Cin)
+    b = randn(Cout, seed=72) if bias else None
+    r = randn(B, Cout, H, W, seed=73) if res else None
+    ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1) + (0 if r is None else r.double())
+    out = ops.conv2d_small_cout(x.to(dev), w.to(dev), None if b is None else b.to(dev), None if r is None else r.to(dev))
+    check(out, ref, 2e-6, "small_cout")
+    assert ops.small_cout_supported(Cout, 3, 3, 1, (1, 1)) and not ops.small_cout_supported(Cout, 3, 3, 2, (1, 1)) and not ops.small_cout_supported(8, 3, 3, 1, (1, 1))
+    m = Conv2d(Cin, Cout, 3, padding=1, bias=bias)                              # the module routes there by itself
+    m.load_state_dict({"weight": w, **({"bias": b} if bias else {})}, dev)
+    y = m(x.to(dev), res=None if r is None else r.to(dev))
+    assert torch.equal(y, out)
