@@ -22,10 +22,17 @@ _CODES = {np.dtype(v): k for k, v in _DTYPES.items()}
 GZIP_LEVEL = 2
 
 
-def _open(path, mode):
-    if str(path).endswith(".gz"):
-        return gzip.open(path, mode, compresslevel=GZIP_LEVEL) if "w" in mode else gzip.open(path, mode)
-    return open(path, mode)
+def _read_all(path):
+    """whole file in, ONE decompress call: the gzip module's buffered reader made ~220 small GIL-holding calls per 2 MB volume, which with 16
+    reader threads turned 25 ms of inflate into 0.27 s per frame (profiles/r03_api_split.md)"""
+    with open(path, "rb") as f:
+        raw = f.read()
+    return gzip.decompress(raw) if str(path).endswith(".gz") else raw
+
+
+def _write_all(path, data):
+    with open(path, "wb") as f:
+        f.write(gzip.compress(data, compresslevel=GZIP_LEVEL) if str(path).endswith(".gz") else data)
 
 
 def write_nifti(path, array, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=(1, 0, 0, 0, 1, 0, 0, 0, 1)):
@@ -55,16 +62,12 @@ def write_nifti(path, array, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), di
     for r in range(3):
         struct.pack_into("<4f", hdr, 280 + 16 * r, float(A[r, 0]), float(A[r, 1]), float(A[r, 2]), float(t[r]))
     hdr[344:348] = b"n+1\0"
-    with _open(path, "wb") as f:
-        f.write(bytes(hdr))
-        f.write(b"\0\0\0\0")
-        f.write(np.ascontiguousarray(a).tobytes())
+    _write_all(path, bytes(hdr) + b"\0\0\0\0" + np.ascontiguousarray(a).tobytes())
 
 
 def read_nifti(path):
     """-> (array [Z,Y,X], {'itk_spacing','itk_origin','itk_direction'})."""
-    with _open(path, "rb") as f:
-        raw = f.read()
+    raw = _read_all(path)
     if struct.unpack_from("<i", raw, 0)[0] != 348:
         raise ValueError("%s: not a little-endian NIfTI-1 file" % path)
     dim = struct.unpack_from("<8h", raw, 40)

@@ -925,6 +925,16 @@ static int f16s_wide() {
     return v;
 }
 
+// CF_F16S_WIDE_PAD=0: only Cout % 128 == 0 takes the 128-channel workgroup shapes.  Default: also a Cout whose last 128-channel block is at
+// least three quarters full (the U-Net's 480 = 3 x 128 + 96): the packed weights are padded to whole 128-channel blocks anyway
+// (pack_conv_weight_f16s: an even number of 64-channel pairs), the rows past Cout are zero weights whose stores the epilogue drops.
+static int f16s_wide_pad() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("CF_F16S_WIDE_PAD"); v = e ? atoi(e) : 1; }
+    return v;
+}
+static bool f16s_cout_wide(int cout) { return cout % 128 == 0 || (f16s_wide_pad() && cout > 128 && cout % 128 >= 96); }
+
 static int f16s_small_tile() {
     static int v = -1;
     if (v < 0) {
@@ -1010,7 +1020,7 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     const bool narrow = p.Cout <= 32;
     const bool small = f16s_small_tile() != 0;
     const bool s2 = k3 && p.stride == 2;
-    const bool wide = small && !s2 && f16s_wide() && p.Cout % 128 == 0 && f16s_loader_waves() == 0;
+    const bool wide = small && !s2 && f16s_wide() && f16s_cout_wide(p.Cout) && f16s_loader_waves() == 0;
     // n-tiles (of 32 output pixels) per workgroup
     const int NT_WG = s2 ? ((small && !narrow) ? 2 : 4) : ((small || sep) ? 4 : 8);
     F16sGeom g;
@@ -1060,8 +1070,8 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     // Measured (profiles/r02_conv_weight_path.md, B = 16): 64 -> 64 at 256x256 234 -> 263 TF, 32 -> 32 195 -> 205, 81 -> 64 208 -> 222; the
     // 128-channel form of it (4 m-tiles x 2 pixel tiles per wave, 8 waves) LOSES to the four-wave shape whose fragments feed 12 MFMAs
     // (128 -> 128 at 128x128: 294 vs 343 TF) and is not dispatched (CF_F16S_WL=2 forces it for A/B runs).
-    if (k3 && p.stride == 1 && f16s_wl() && small && f16s_loader_waves() == 0 && (p.Cout % 128 != 0 || f16s_wl() == 2)) {
-        const bool w128 = p.Cout % 128 == 0;
+    if (k3 && p.stride == 1 && f16s_wl() && small && f16s_loader_waves() == 0 && (!f16s_cout_wide(p.Cout) || f16s_wl() == 2)) {
+        const bool w128 = f16s_cout_wide(p.Cout);
         geometry(w128 ? 128 : 256);
         if (g.NIMG == 1) {
             const int rc = w128 ? launch_f16s_wl<4, 2>(p, g, one_sample_per_wg ? nullptr : wpk, s, one_sample_per_wg)
@@ -1086,14 +1096,14 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
         // halves the per-wave weight re-reads from L1/L2 -- the resource the time stamps and the persistent-kernel experiment pointed at
         // (+9-15 % on the 128- and 256-channel layers at 64x64 and above); 148 VGPRs (no scratch under a 2-workgroup launch bound; a bound of 3 made the allocator spill 168 B/lane for the same speed), 3 waves/SIMD.  With few workgroups (32x32 maps)
         // the 8-wave shape (4 m-tiles x 2 pixel groups, 4 waves/SIMD) keeps more of the chip busy.  CF_F16S_WIDE=2 / 3 force one.
-        const long nwg = (long)g.tiles_x * g.tiles_y * g.bgroups * (p.Cout / 128);
+        const long nwg = (long)g.tiles_x * g.tiles_y * g.bgroups * ((p.Cout + 127) / 128);
         const int mode = f16s_wide();
         const bool four = mode == 2 || (mode == 1 && nwg >= 1024 && g.NIMG == 1);
         if (four && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 <= 2) return launch_f16s<3, 3, 16, 4, 4, 2, 0, 4>(p, g, wpk, s);
         return launch_f16s<3, 3, 16, 4, 2, 2, 0, 8>(p, g, wpk, s);
     }
     if (wide) {   // 1x1: same choice between the two 128-channel shapes
-        const long nwg = (long)g.tiles_x * g.tiles_y * g.bgroups * (p.Cout / 128);
+        const long nwg = (long)g.tiles_x * g.tiles_y * g.bgroups * ((p.Cout + 127) / 128);
         static int k1four = -1;
         if (k1four < 0) { const char* e = getenv("CF_F16S_K1FOUR"); k1four = e ? atoi(e) : 1; }
         if (k1four && nwg >= 1024 && g.NIMG == 1 && (g.NIMG * g.PH * g.PW * (CK / 8) + 255) / 256 <= 2) return launch_f16s<1, 1, 32, 4, 4, 2, 0, 4>(p, g, wpk, s);
@@ -1107,7 +1117,7 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     if (small && narrow && !s2) return k3 ? launch_f16s<3, 3, 16, 1, 1, 2>(p, g, wpk, s) : launch_f16s<1, 1, 32, 1, 1, 2>(p, g, wpk, s);
     // stride 2 with Cout % 128 == 0: four m-tiles x two pixel tiles per wave -- every weight fragment is loaded once per workgroup and
     // feeds 6 MFMAs (the 64-channel shape below: loaded twice, 3 MFMAs each)
-    if (small && s2 && !narrow && p.Cout % 128 == 0 && f16s_wide()) return launch_f16s<3, 3, 16, 4, 2, 3>(p, g, wpk, s);
+    if (small && s2 && !narrow && f16s_cout_wide(p.Cout) && f16s_wide()) return launch_f16s<3, 3, 16, 4, 2, 3>(p, g, wpk, s);
     if (small && s2 && !narrow) return launch_f16s<3, 3, 16, 2, 1, 3>(p, g, wpk, s);
     if (small && !narrow) return k3 ? launch_f16s<3, 3, 16, 2, 2, 2>(p, g, wpk, s) : launch_f16s<1, 1, 32, 2, 2, 2>(p, g, wpk, s);
     if (k3) {

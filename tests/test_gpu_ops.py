@@ -429,6 +429,7 @@ def test_conv2d_f16s_channel_tail_never_reads_the_next_sample(dev, C1, C2, H, W,
     (2, 16, 32, 32, 64, 3, 1, 8),      # GroupNorm(8, 64): 8 channels per group
     (3, 32, 64, 64, 32, 3, 1, 32),     # InstanceNorm (one channel per group), narrow kernel variant
     (2, 64, 64, 64, 128, 3, 2, 8),     # stride 2, 16 channels per group
+    (3, 256, 32, 32, 480, 3, 2, 480),  # stride 2 to 480 channels (128-channel stride-2 shape, padded last block), InstanceNorm
     (2, 48, 40, 56, 256, 1, 1, 8),     # 1x1, 32 channels per group, ragged spatial
     (5, 24, 8, 8, 96, 3, 1, 96),       # 8x8 maps: several samples per workgroup -> statistics pass fallback
     (2, 64, 33, 47, 512, 3, 1, 8),     # 64 channels per group: a group spans two m-tiles / workgroups
@@ -459,6 +460,8 @@ def test_conv_f16s_fused_group_norm_statistics(dev, B, Cin, H, W, Cout, k, strid
     (9, 16, 16, 128, 96, 128, 8),      # cat input, 128-channel (8-wave) workgroups
     (40, 16, 0, 64, 64, 32, 32),       # narrow variant, 1280 tiles, InstanceNorm statistics
     (11, 16, 0, 100, 132, 64, 8),      # ragged tiles (100 rows, 132 columns)
+    (70, 48, 48, 32, 32, 480, 480),    # cat input -> 480 channels (padded to 4 x 128-channel blocks), InstanceNorm statistics, 1120 workgroups
+    (6, 64, 0, 64, 64, 480, 8),        # 60 channels per group: groups straddle the 128-channel blocks, the last block ends at channel 480
 ])
 def test_conv_f16s_many_tiles(dev, B, C1, C2, H, W, Cout, groups):
     """Launches with more tiles than resident workgroups (several dispatch rounds, XCD-banded tile order, vector staging at the
@@ -491,6 +494,8 @@ def test_conv_f16s_many_tiles(dev, B, C1, C2, H, W, Cout, groups):
     (2, 64, 48, 64, 64),       # 64-channel shape, ragged rows
     (32, 128, 64, 64, 128),    # 128-channel four-wave shape (>= 1024 workgroups)
     (2, 480, 16, 16, 480),     # channel tail (480 = 30 chunks), 16-wide rows
+    (140, 480, 16, 16, 480),   # 480 = 3 x 128 + 96 output channels on the four-wave 128-channel shape (>= 1024 workgroups), last block 3/4 full
+    (3, 224, 32, 32, 224),     # 224 = 128 + 96 on the eight-wave 128-channel shape
 ])
 def test_conv_f16s_prenorm(dev, B, C, H, W, Cout):
     """convolution that applies its input's deferred InstanceNorm + LeakyReLU while staging, against torch on the materialised
@@ -910,7 +915,7 @@ def test_conv_small_cout_direct(dev, B, Cin, H, W, Cout, bias, res):
     r = randn(B, Cout, H, W, seed=73) if res else None
     ref = F.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1) + (0 if r is None else r.double())
     out = ops.conv2d_small_cout(x.to(dev), w.to(dev), None if b is None else b.to(dev), None if r is None else r.to(dev))
-    check(out, ref, 2e-6, "small_cout")
+    check(out, ref, 2e-5, "small_cout")          # fp32 accumulation over 9 * Cin terms
     assert ops.small_cout_supported(Cout, 3, 3, 1, (1, 1)) and not ops.small_cout_supported(Cout, 3, 3, 2, (1, 1)) and not ops.small_cout_supported(8, 3, 3, 1, (1, 1))
     m = Conv2d(Cin, Cout, 3, padding=1, bias=bias)                              # the module routes there by itself
     m.load_state_dict({"weight": w, **({"bias": b} if bias else {})}, dev)
