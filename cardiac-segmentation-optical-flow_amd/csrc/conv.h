@@ -37,6 +37,10 @@ int launch_conv(const ConvParams& p, hipStream_t s);
 bool conv_f16s_supported(const ConvParams& p);
 int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s);
 
+// persistent software-pipelined variant of the f16-split kernel for short-K layers on large maps (conv_stream.hip); the caller zeroes p.gn_ws
+bool conv_stream_applicable(const ConvParams& p);
+int launch_conv_stream(const ConvParams& p, const _Float16* wpk, hipStream_t s);
+
 // RAFT all-pairs volume + pyramid in one kernel (allpairs.hip); returns 1 when the shape is not one it is built for
 int allpairs_pyramid_fused(const float* f1, const float* f2, float* pyr, int B, int C, int H, int W, int levels, hipStream_t stream);
 

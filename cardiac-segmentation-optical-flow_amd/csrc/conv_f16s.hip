@@ -950,6 +950,14 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
 // GroupNorm statistics of the output -- from the fused epilogue when every workgroup covers a single sample, otherwise from the
 // separate statistics pass.
 static int launch_conv_f16s_part(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
+    // short-K layers on large maps (<= 64 output channels, 3x3, stride 1, >= 1024 tiles): the persistent pipelined kernel of conv_stream.hip,
+    // same arithmetic and packed weights (CF_CONV_STREAM=0 keeps this file's shapes: A/B knob)
+    if (conv_stream_applicable(p)) {
+        if (p.probe) return CF_OK;
+        if (p.gn_ws && !p.gn_prezeroed &&
+            hipMemsetAsync(p.gn_ws, 0, sizeof(double) * 2 * (size_t)p.B * p.gn_groups, s) != hipSuccess) { set_error("conv_stream: memset failed"); return CF_ERR_LAUNCH; }
+        return launch_conv_stream(p, wpk, s);
+    }
     if (!p.gn_ws) return launch_conv_f16s_impl(p, wpk, s, nullptr);
     bool fusable = false;
     launch_conv_f16s_impl(p, nullptr, s, &fusable);  // geometry probe only
@@ -990,6 +998,7 @@ static long f16s_sub_batch(const ConvParams& p) {
 }
 
 int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
+    if (conv_stream_applicable(p)) return launch_conv_f16s_part(p, wpk, s);      // per-sample buffer resources: no 2 GiB limit on the batch
     const long HW = (long)p.H * p.W;
     const long nb = f16s_sub_batch(p);
     if (nb < 1) { set_error("conv_f16s: one sample of the input exceeds 2 GiB"); return CF_ERR_ARG; }
@@ -1178,10 +1187,10 @@ extern "C" int cf_conv2d_f16s_prenorm_ok(int B, int C, int H, int W, int Cout) {
     if (nb < 1) return 0;
     const long last = B - (B - 1) / nb * nb;
     p.B = (int)nb;
-    if (launch_conv_f16s_impl(p, reinterpret_cast<const _Float16*>(dummy), nullptr, nullptr) != CF_OK) return 0;
+    if (!conv_stream_applicable(p) && launch_conv_f16s_impl(p, reinterpret_cast<const _Float16*>(dummy), nullptr, nullptr) != CF_OK) return 0;
     if (last != nb) {
         p.B = (int)last;
-        if (launch_conv_f16s_impl(p, reinterpret_cast<const _Float16*>(dummy), nullptr, nullptr) != CF_OK) return 0;
+        if (!conv_stream_applicable(p) && launch_conv_f16s_impl(p, reinterpret_cast<const _Float16*>(dummy), nullptr, nullptr) != CF_OK) return 0;
     }
     return 1;
 }

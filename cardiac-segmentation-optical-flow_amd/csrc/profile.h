@@ -18,7 +18,8 @@ enum ProfileKernel {
     PK_GN_APPLY = 10,                                        // GroupNorm apply passes; work = algorithmic bytes
     PK_WARP = 11, PK_WARP_LABELS = 12, PK_JACOBIAN = 13,     // VoxelMorph warp family (2-D); work = algorithmic bytes
     PK_CONV_SMALL_COUT = 14,                                 // direct 3x3 convolution to <= 4 output channels (flow heads); work = algorithmic bytes
-    PK_COUNT = 15
+    PK_CONV_STREAM = 15,                                     // conv_stream_kernel (same arithmetic as PK_CONV_F16S); work = flops
+    PK_COUNT = 16
 };
 
 bool profile_on();

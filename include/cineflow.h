@@ -173,6 +173,10 @@ int cf_group_norm_coef(const double* ws, const float* gamma, const float* beta, 
  * in channel order; w is the [K][C] weight, bias may be NULL. */
 int cf_norm_head_1x1(const float* x, const float* coef, float slope, const float* w, const float* bias, float* out, int B, int C, int HW,
                      int K, void* stream);
+/* Tuning / A-B knob without a reference counterpart: the short-K layers on large maps (3x3, stride 1, 32 or 64 output channels, >= 1024 tiles of
+ * 8 x 32 pixels) run on a persistent software-pipelined kernel (csrc/conv_stream.hip) whose outputs are bit-identical to the
+ * one-tile-per-workgroup kernel's; cf_conv_stream_enable(0) routes them back (also CF_CONV_STREAM=0).  Returns the previous setting. */
+int cf_conv_stream_enable(int on);
 int cf_conv2d_f16s_prenorm_ok(int B, int C, int H, int W, int Cout);
 int cf_conv2d_f16s_prenorm(const float* x, int C, const float* in_norm, float in_slope, const void* wpk, const float* bias, float* out,
                            int B, int H, int W, int Cout, float alpha, double* gn_ws, int gn_groups, void* stream);

@@ -921,3 +921,81 @@ def test_conv_small_cout_direct(dev, B, Cin, H, W, Cout, bias, res):
     m.load_state_dict({"weight": w, **({"bias": b} if bias else {})}, dev)
     y = m(x.to(dev), res=None if r is None else r.to(dev))
     assert torch.equal(y, out)
+
+
+# ------------------------------------------------------------------------------------------------ conv_stream.hip (persistent pipelined kernel)
+STREAM_CASES = [   # B, C1, C2, H, W, Cout, groups
+    (20, 64, 0, 128, 128, 64, 8),      # 1280 tiles = 5 per workgroup (odd), 4 chunks
+    (16, 32, 0, 128, 128, 32, 32),     # 1024 tiles = 4 per workgroup, narrow (one m-tile), 2 chunks, InstanceNorm statistics
+    (18, 32, 32, 128, 128, 32, 32),    # cat input, narrow
+    (12, 64, 64, 128, 160, 64, 8),     # cat input, 5 tile columns
+    (12, 81, 0, 128, 128, 64, 8),      # 81 channels: 6 chunks, zero-weight channel tail
+    (10, 20, 28, 100, 132, 64, 8),     # split-aware packing (C1 = 20 padded to 2 chunks), ragged rows (100 = 12.5 tiles) and columns (132)
+    (3, 64, 0, 256, 256, 64, 8),       # 768 tiles: below the threshold -> stays on conv_f16s (the knob must change nothing)
+]
+
+
+@pytest.mark.parametrize("B,C1,C2,H,W,Cout,groups", STREAM_CASES)
+def test_conv_stream_bit_identical_to_conv_f16s(dev, B, C1, C2, H, W, Cout, groups):
+    """The persistent software-pipelined kernel (csrc/conv_stream.hip) against the one-tile-per-workgroup kernel on the same packed weights:
+    same k order and 3-term products into one fp32 accumulator -> bit-identical outputs; fused GroupNorm statistics equal up to the order
+    in which fp32 partial sums meet; one sample against an fp64 convolution."""
+    from cineflow import ops
+    from cineflow._lib import lib
+    x1 = randn(B, C1, H, W, seed=80).to(dev)
+    x2 = randn(B, C2, H, W, seed=81).to(dev) if C2 else None
+    w = randn(Cout, C1 + C2, 3, 3, seed=82) / math.sqrt((C1 + C2) * 9)
+    b = randn(Cout, seed=83).to(dev)
+    wpk, ws = ops.pack_conv_weight_f16s(w.to(dev), c1=C1 if (C2 and C1 % 16) else None)
+    prev = lib().cf_conv_stream_enable(0)
+    try:
+        ref_out, ref_st = ops.conv2d_f16s(x1, wpk, ws, b, Cout, 3, 3, 1, (1, 1), x2=x2, stats_groups=groups)
+        ref_plain = ops.conv2d_f16s(x1, wpk, ws, None, Cout, 3, 3, 1, (1, 1), x2=x2)
+        lib().cf_conv_stream_enable(1)
+        out, st = ops.conv2d_f16s(x1, wpk, ws, b, Cout, 3, 3, 1, (1, 1), x2=x2, stats_groups=groups)
+        plain = ops.conv2d_f16s(x1, wpk, ws, None, Cout, 3, 3, 1, (1, 1), x2=x2)
+        again, st2 = ops.conv2d_f16s(x1, wpk, ws, b, Cout, 3, 3, 1, (1, 1), x2=x2, stats_groups=groups)
+    finally:
+        lib().cf_conv_stream_enable(prev)
+    assert torch.equal(out, ref_out) and torch.equal(plain, ref_plain) and torch.equal(again, out)
+    scale = ref_out.double().abs().view(B, groups, -1).sum(-1)[..., None] + 1.0
+    for s_ in (st, st2):
+        assert float(((s_.view(B, groups, 2) - ref_st.view(B, groups, 2)).abs() / scale).max()) <= 2e-6
+    xin = x1[-1:].cpu() if x2 is None else torch.cat([x1[-1:].cpu(), x2[-1:].cpu()], 1)
+    ref = F.conv2d(xin.double(), w.double(), b.cpu().double(), padding=1)
+    check(out[-1:], ref, 1e-5, "conv_stream vs fp64")
+
+
+@pytest.mark.parametrize("B,C,H,W,Cout,act", [(20, 64, 128, 128, 64, "gelu"), (16, 32, 128, 128, 32, "lrelu"), (12, 128, 128, 128, 64, "gelu"),
+                                              (10, 96, 104, 136, 64, "lrelu")])
+def test_conv_stream_prenorm_bit_identical(dev, B, C, H, W, Cout, act):
+    """deferred input normalisation (GroupNorm / InstanceNorm + GELU / LeakyReLU applied while the tile is staged) in the persistent kernel: the
+    coefficient table is double buffered per tile because consecutive tiles of a workgroup belong to different samples"""
+    from cineflow import ops
+    from cineflow._lib import lib
+    groups = 8 if act == "gelu" else C
+    raw = (randn(B, C, H, W, seed=84) * (1.0 + 0.2 * torch.arange(B).view(B, 1, 1, 1)) + 0.1 * torch.arange(B).view(B, 1, 1, 1)).to(dev)   # per-sample statistics differ
+    w = (randn(Cout, C, 3, 3, seed=85) / math.sqrt(9 * C)).to(dev)
+    b = randn(Cout, seed=86).to(dev)
+    gam, bet = (1 + 0.1 * randn(C, seed=87)).to(dev), (0.1 * randn(C, seed=88)).to(dev)
+    wpk, wsc = ops.pack_conv_weight_f16s(w)
+    wsum = torch.stack([raw.double().sum((2, 3)), (raw.double() ** 2).sum((2, 3))], dim=2).view(B, groups, C // groups, 2).sum(2).reshape(-1).contiguous()
+    coef = ops.group_norm_coef(wsum, gam, bet, groups, B, C, H * W)
+    slope = -1.0 if act == "gelu" else 0.01
+    og = Cout if act == "lrelu" else 8
+    prev = lib().cf_conv_stream_enable(0)
+    try:
+        assert ops.prenorm_ok(raw, Cout)
+        ref_out, ref_st = ops.conv2d_f16s_prenorm(raw, coef, slope, wpk, wsc, b, Cout, stats_groups=og)
+        lib().cf_conv_stream_enable(1)
+        assert ops.prenorm_ok(raw, Cout)
+        out, st = ops.conv2d_f16s_prenorm(raw, coef, slope, wpk, wsc, b, Cout, stats_groups=og)
+    finally:
+        lib().cf_conv_stream_enable(prev)
+    assert torch.equal(out, ref_out)
+    scale = ref_out.double().abs().view(B, og, -1).sum(-1)[..., None] + 1.0
+    assert float(((st.view(B, og, 2) - ref_st.view(B, og, 2)).abs() / scale).max()) <= 2e-6
+    i = B - 1
+    xn = F.group_norm(raw[i:i + 1].cpu().double(), groups, gam.cpu().double(), bet.cpu().double(), 1e-5)
+    xn = F.gelu(xn) if act == "gelu" else F.leaky_relu(xn, 0.01)
+    check(out[i:i + 1], F.conv2d(xn, w.cpu().double(), b.cpu().double(), padding=1), 2e-5, "conv_stream prenorm vs fp64")
