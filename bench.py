@@ -269,6 +269,9 @@ def hbm_roofline(name, rec, pmc=None):
 def conv_roofline(h, dt):
     """roofline of the dominant convolution kernel from the per-launch event pairs recorded during the timed steps"""
     conv = [read_profile(h, k) for k in (0, 1, 2, 6)]
+    stream = read_profile(h, 15)          # conv_stream_kernel: the persistent variant of the same 3-term algorithm for the 32 / 64-channel layers
+    one_tile = conv[3]
+    conv[3] = tuple(a + b for a, b in zip(conv[3], stream))
     dom = max(range(4), key=lambda i: conv[i][0])
     ms, flops, n = conv[dom]
     if not n:
@@ -277,7 +280,10 @@ def conv_roofline(h, dt):
     if dom == 3:
         # the f16 hi/lo-split kernel issues 3 f16 MFMAs per algorithmic MAC: priced against the dense f16 MFMA peak,
         # its ceiling is 1/3; `mfma_issue_frac` is the fraction of the f16 MFMA peak the issued MFMAs reach
-        return {"bound": "mfma", "kernel": "conv_f16s_kernel (f16 MFMA, 3-term hi/lo split, fp32 accumulate)", "achieved": round(ach, 3),
+        per = {nm: {"TFLOP/s": round(r[1] / (r[0] * 1e-3) / 1e12, 1), "launches": r[2], "avg_launch_us": round(r[0] * 1e3 / r[2], 2),
+                    "share_of_step_time": round(r[0] * 1e-3 / dt, 3)} for nm, r in (("conv_f16s_kernel", one_tile), ("conv_stream_kernel", stream)) if r[2]}
+        return {"bound": "mfma", "kernel": "conv_f16s_kernel + conv_stream_kernel (f16 MFMA, 3-term hi/lo split, fp32 accumulate; one tile per workgroup / "
+                                           "persistent for 32- and 64-channel layers)", "per_kernel": per, "achieved": round(ach, 3),
                 "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4),
                 "mfma_issue_frac": round(3 * ach / MFMA_F16_PEAK_TFLOPS, 4), "vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 3),
                 "sustained_mfma_peak_measured": MFMA_F16_SUSTAINED_TFLOPS, "mfma_issue_frac_of_sustained": round(3 * ach / MFMA_F16_SUSTAINED_TFLOPS, 4),

@@ -174,8 +174,10 @@ int cf_group_norm_coef(const double* ws, const float* gamma, const float* beta, 
 int cf_norm_head_1x1(const float* x, const float* coef, float slope, const float* w, const float* bias, float* out, int B, int C, int HW,
                      int K, void* stream);
 /* Tuning / A-B knob without a reference counterpart: the short-K layers on large maps (3x3, stride 1, 32 or 64 output channels, >= 1024 tiles of
- * 8 x 32 pixels) run on a persistent software-pipelined kernel (csrc/conv_stream.hip) whose outputs are bit-identical to the
- * one-tile-per-workgroup kernel's; cf_conv_stream_enable(0) routes them back (also CF_CONV_STREAM=0).  Returns the previous setting. */
+ * 16 / 8 rows x 32 pixels) run on a persistent software-pipelined kernel (csrc/conv_stream.hip) that sums the taps of a chunk in (kx, ky)
+ * instead of (ky, kx) order: outputs equal the one-tile-per-workgroup kernel's to fp32 summation-order noise (<= 4e-6 of the output scale).
+ * level 0 routes everything back to conv_f16s (also CF_CONV_STREAM=0), 1 (default) takes the shapes measured faster there (all but the
+ * 64-channel layers with deferred input normalisation), 2 every shape the kernel can run.  Returns the previous level. */
 int cf_conv_stream_enable(int on);
 int cf_conv2d_f16s_prenorm_ok(int B, int C, int H, int W, int Cout);
 int cf_conv2d_f16s_prenorm(const float* x, int C, const float* in_norm, float in_slope, const void* wpk, const float* bias, float* out,

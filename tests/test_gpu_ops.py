@@ -926,8 +926,9 @@ def test_conv_small_cout_direct(dev, B, Cin, H, W, Cout, bias, res):
 # ------------------------------------------------------------------------------------------------ conv_stream.hip (persistent pipelined kernel)
 STREAM_CASES = [   # B, C1, C2, H, W, Cout, groups
     (20, 64, 0, 128, 128, 64, 8),      # 1280 tiles = 5 per workgroup (odd), 4 chunks
-    (16, 32, 0, 128, 128, 32, 32),     # 1024 tiles = 4 per workgroup, narrow (one m-tile), 2 chunks, InstanceNorm statistics
-    (18, 32, 32, 128, 128, 32, 32),    # cat input, narrow
+    (32, 32, 0, 128, 128, 32, 32),     # 1024 tiles (16 rows each) = 4 per workgroup, narrow (one m-tile), 2 chunks, InstanceNorm statistics
+    (34, 32, 32, 128, 128, 32, 32),    # cat input, narrow
+    (33, 32, 0, 120, 132, 32, 32),     # narrow, ragged rows (120 = 7.5 tiles) and columns
     (12, 64, 64, 128, 160, 64, 8),     # cat input, 5 tile columns
     (12, 81, 0, 128, 128, 64, 8),      # 81 channels: 6 chunks, zero-weight channel tail
     (10, 20, 28, 100, 132, 64, 8),     # split-aware packing (C1 = 20 padded to 2 chunks), ragged rows (100 = 12.5 tiles) and columns (132)
@@ -936,10 +937,10 @@ STREAM_CASES = [   # B, C1, C2, H, W, Cout, groups
 
 
 @pytest.mark.parametrize("B,C1,C2,H,W,Cout,groups", STREAM_CASES)
-def test_conv_stream_bit_identical_to_conv_f16s(dev, B, C1, C2, H, W, Cout, groups):
-    """The persistent software-pipelined kernel (csrc/conv_stream.hip) against the one-tile-per-workgroup kernel on the same packed weights:
-    same k order and 3-term products into one fp32 accumulator -> bit-identical outputs; fused GroupNorm statistics equal up to the order
-    in which fp32 partial sums meet; one sample against an fp64 convolution."""
+def test_conv_stream_matches_conv_f16s(dev, B, C1, C2, H, W, Cout, groups):
+    """The persistent row-sharing kernel (csrc/conv_stream.hip) against the one-tile-per-workgroup kernel on the same packed weights: the same
+    3-term products into one fp32 accumulator, taps summed in (kx, ky) instead of (ky, kx) order -> equal to fp32 summation-order noise
+    (<= 4e-6 of the output scale), deterministic run to run; fused GroupNorm statistics likewise; one sample against an fp64 convolution."""
     from cineflow import ops
     from cineflow._lib import lib
     x1 = randn(B, C1, H, W, seed=80).to(dev)
@@ -951,13 +952,14 @@ def test_conv_stream_bit_identical_to_conv_f16s(dev, B, C1, C2, H, W, Cout, grou
     try:
         ref_out, ref_st = ops.conv2d_f16s(x1, wpk, ws, b, Cout, 3, 3, 1, (1, 1), x2=x2, stats_groups=groups)
         ref_plain = ops.conv2d_f16s(x1, wpk, ws, None, Cout, 3, 3, 1, (1, 1), x2=x2)
-        lib().cf_conv_stream_enable(1)
+        lib().cf_conv_stream_enable(2)
         out, st = ops.conv2d_f16s(x1, wpk, ws, b, Cout, 3, 3, 1, (1, 1), x2=x2, stats_groups=groups)
         plain = ops.conv2d_f16s(x1, wpk, ws, None, Cout, 3, 3, 1, (1, 1), x2=x2)
         again, st2 = ops.conv2d_f16s(x1, wpk, ws, b, Cout, 3, 3, 1, (1, 1), x2=x2, stats_groups=groups)
     finally:
         lib().cf_conv_stream_enable(prev)
-    assert torch.equal(out, ref_out) and torch.equal(plain, ref_plain) and torch.equal(again, out)
+    tol = 4e-6 * (1.0 + float(ref_out.abs().max()))
+    assert float((out - ref_out).abs().max()) <= tol and float((plain - ref_plain).abs().max()) <= tol and torch.equal(again, out)
     scale = ref_out.double().abs().view(B, groups, -1).sum(-1)[..., None] + 1.0
     for s_ in (st, st2):
         assert float(((s_.view(B, groups, 2) - ref_st.view(B, groups, 2)).abs() / scale).max()) <= 2e-6
@@ -966,9 +968,9 @@ def test_conv_stream_bit_identical_to_conv_f16s(dev, B, C1, C2, H, W, Cout, grou
     check(out[-1:], ref, 1e-5, "conv_stream vs fp64")
 
 
-@pytest.mark.parametrize("B,C,H,W,Cout,act", [(20, 64, 128, 128, 64, "gelu"), (16, 32, 128, 128, 32, "lrelu"), (12, 128, 128, 128, 64, "gelu"),
+@pytest.mark.parametrize("B,C,H,W,Cout,act", [(20, 64, 128, 128, 64, "gelu"), (32, 32, 128, 128, 32, "lrelu"), (12, 128, 128, 128, 64, "gelu"),
                                               (10, 96, 104, 136, 64, "lrelu")])
-def test_conv_stream_prenorm_bit_identical(dev, B, C, H, W, Cout, act):
+def test_conv_stream_prenorm_matches(dev, B, C, H, W, Cout, act):
     """deferred input normalisation (GroupNorm / InstanceNorm + GELU / LeakyReLU applied while the tile is staged) in the persistent kernel: the
     coefficient table is double buffered per tile because consecutive tiles of a workgroup belong to different samples"""
     from cineflow import ops
@@ -987,12 +989,12 @@ def test_conv_stream_prenorm_bit_identical(dev, B, C, H, W, Cout, act):
     try:
         assert ops.prenorm_ok(raw, Cout)
         ref_out, ref_st = ops.conv2d_f16s_prenorm(raw, coef, slope, wpk, wsc, b, Cout, stats_groups=og)
-        lib().cf_conv_stream_enable(1)
+        lib().cf_conv_stream_enable(2)
         assert ops.prenorm_ok(raw, Cout)
         out, st = ops.conv2d_f16s_prenorm(raw, coef, slope, wpk, wsc, b, Cout, stats_groups=og)
     finally:
         lib().cf_conv_stream_enable(prev)
-    assert torch.equal(out, ref_out)
+    assert float((out - ref_out).abs().max()) <= 4e-6 * (1.0 + float(ref_out.abs().max()))
     scale = ref_out.double().abs().view(B, og, -1).sum(-1)[..., None] + 1.0
     assert float(((st.view(B, og, 2) - ref_st.view(B, og, 2)).abs() / scale).max()) <= 2e-6
     i = B - 1
