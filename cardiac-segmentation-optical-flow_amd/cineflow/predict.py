@@ -683,8 +683,12 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
 
     finishing = deque()                                                          # exports in flight: (seg_paths, reg_paths, jobs, output files)
     try:
-        # slices of a patient are only known after preprocessing; groups are filled greedily in patient order
-        submit_more(4)
+        # slices of a patient are only known after preprocessing; groups are filled greedily in patient order.  The pool runs `ahead` patients
+        # in front of the collector: at least one whole device batch more than the group being assembled, so that the frames of the NEXT
+        # group are read and cropped while this one is on the device (with 4 the second half of the next group was only submitted after
+        # the device batch had finished: 3.4 of 10.5 s of the 16-patient API bench were spent waiting for it, profiles/r03_api_split.md)
+        ahead = 8
+        submit_more(ahead)
         carry = None
         while submitted or carry is not None:
             group, nslices = [], 0
@@ -696,7 +700,7 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
                     timing["preprocess_wait_s"] += time.perf_counter() - t0
                     timing["preprocess_work_s"] += sum(g[1] for g in got)
                     carry = (ci, [g[0] for g in got])
-                    submit_more(4)
+                    submit_more(ahead)
                 z = carry[1][0][0].shape[1]
                 if group and nslices + z > max_slices:
                     break
@@ -706,6 +710,8 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
             t0 = time.perf_counter()
             unl = [np.stack([p_[0] for p_ in pre]) + 1e-8 for _ci, pre in group]      # predict.py:1025
             print("predicting %d patient(s), %d slices in one device batch" % (len(group), nslices))
+            ahead = max(ahead, 2 * len(group) + 2)
+            submit_more(ahead)
             # the crop-space copies only when the voxelmorph_saver tree is being written; the `raw` tensor (frames + crop-space flow) the
             # reference returns for its trainer's plots is not consumed by the exporter
             results = trainer.predict_patients_flow(unl, do_mirroring=do_tta, mirror_axes=trainer.data_aug_params["mirror_axes"],
