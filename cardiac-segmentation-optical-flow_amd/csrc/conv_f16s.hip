@@ -1029,7 +1029,17 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     const bool narrow = p.Cout <= 32;
     const bool small = f16s_small_tile() != 0;
     const bool s2 = k3 && p.stride == 2;
-    const bool wide = small && !s2 && f16s_wide() && f16s_cout_wide(p.Cout) && f16s_loader_waves() == 0;
+    // Cout = 3 x 128 + 96 and the like ride on the 128-channel shapes with a partly empty last m-tile -- where the four-wave shape runs
+    // (>= 1024 workgroups); a small launch keeps the 64-channel shapes (and with them the deferred input normalisation)
+    bool cout_wide = f16s_cout_wide(p.Cout);
+    if (cout_wide && p.Cout % 128 != 0 && !s2) {
+        const int tw = p.Wo < 32 ? p.Wo : 32;
+        int th = 128 / tw;
+        if (th > p.Ho) th = p.Ho;
+        const long nwg = (long)((p.Wo + tw - 1) / tw) * ((p.Ho + th - 1) / th) * p.B * ((p.Cout + 127) / 128);
+        if (nwg < 1024) cout_wide = false;
+    }
+    const bool wide = small && !s2 && f16s_wide() && cout_wide && f16s_loader_waves() == 0;
     // n-tiles (of 32 output pixels) per workgroup
     const int NT_WG = s2 ? ((small && !narrow) ? 2 : 4) : ((small || sep) ? 4 : 8);
     F16sGeom g;
@@ -1079,8 +1089,8 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
     // Measured (profiles/r02_conv_weight_path.md, B = 16): 64 -> 64 at 256x256 234 -> 263 TF, 32 -> 32 195 -> 205, 81 -> 64 208 -> 222; the
     // 128-channel form of it (4 m-tiles x 2 pixel tiles per wave, 8 waves) LOSES to the four-wave shape whose fragments feed 12 MFMAs
     // (128 -> 128 at 128x128: 294 vs 343 TF) and is not dispatched (CF_F16S_WL=2 forces it for A/B runs).
-    if (k3 && p.stride == 1 && f16s_wl() && small && f16s_loader_waves() == 0 && (!f16s_cout_wide(p.Cout) || f16s_wl() == 2)) {
-        const bool w128 = f16s_cout_wide(p.Cout);
+    if (k3 && p.stride == 1 && f16s_wl() && small && f16s_loader_waves() == 0 && (!cout_wide || f16s_wl() == 2)) {
+        const bool w128 = cout_wide;
         geometry(w128 ? 128 : 256);
         if (g.NIMG == 1) {
             const int rc = w128 ? launch_f16s_wl<4, 2>(p, g, one_sample_per_wg ? nullptr : wpk, s, one_sample_per_wg)
