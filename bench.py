@@ -455,6 +455,10 @@ def bench_api(args, dev, world, rank):
                 write_nifti(os.path.join(inp, pat, "%s_frame%02d_0000.nii.gz" % (pat, t)), frames[t].astype(np.float32), (1.25, 1.25, 10.0), (0.0, 0.0, 0.0))
         log("api: model folder + %d patients x %d frames written to %s in %.1f s" % (npat, T, root, time.perf_counter() - t0))
         threads = host_threads()
+        # pool sizes of the call (the reference's num_threads_preprocessing / num_threads_nifti_save); the calling thread needs a core of
+        # its own for the launch stream, so the two pools share the rest
+        pre_threads = args.pre_threads or max(1, threads // 2)
+        save_threads = args.save_threads or max(1, threads - pre_threads - 2)
 
         def call(tag, n):
             out = os.path.join(root, "out_" + tag)
@@ -462,7 +466,7 @@ def bench_api(args, dev, world, rank):
             os.makedirs(sub)
             for p in range(n):
                 os.symlink(os.path.join(inp, "patient%03d" % p), os.path.join(sub, "patient%03d" % p))
-            P.predict_from_folder(model, sub, out, [0], False, threads, threads, None, 0, 1, True, disable_postprocessing=True)
+            P.predict_from_folder(model, sub, out, [0], False, pre_threads, save_threads, None, 0, 1, True, disable_postprocessing=True)
             tim = dict(P.LAST_TIMING)
             shutil.rmtree(out)
             return tim
@@ -492,7 +496,8 @@ def bench_api(args, dev, world, rank):
             "config": {"workload": "predict_from_folder (nnunet/inference/predict.py:665-780 API) on %d synthetic patients x %d slices x %d frames x 256x256 "
                                    "from gzip NIfTI files in tmpfs: read + preprocess, Generic_UNet 4-flip TTA + SegFlowGaussian(video.yaml) + label warp with "
                                    "up to %d slices of several patients per device batch, NIfTI / NPZ export; host work INSIDE the timed region" % (npat, Z, T, P.MAX_SLICES_PER_LAUNCH),
-                       "patients_per_step_per_gpu": npat, "slices_per_patient": Z, "frames_per_slice": T, "host_threads": threads},
+                       "patients_per_step_per_gpu": npat, "slices_per_patient": Z, "frames_per_slice": T, "host_threads": threads,
+                       "num_threads_preprocessing": pre_threads, "num_threads_nifti_save": save_threads},
             "wall_time_split_per_step": split,
             "note": "preprocess_wait / device / export_wait are what the calling thread spent blocked in each stage (they add up to total); *_work are summed "
                     "thread times of the background pools; the device-only rate of the same networks is the default variant's `value`",
@@ -535,6 +540,8 @@ def main():
     ap.add_argument("--frames", type=int, default=30, help="frames per cine slice (T)")
     ap.add_argument("--pairs", type=int, default=None, help="frame pairs per step and per GPU (default: 128 for raft, 960 for warp)")
     ap.add_argument("--patients", type=int, default=16, help="api variant: synthetic patients (8 slices each) per step and per GPU")
+    ap.add_argument("--pre-threads", type=int, default=0, help="api variant: num_threads_preprocessing (default: half the host threads)")
+    ap.add_argument("--save-threads", type=int, default=0, help="api variant: num_threads_nifti_save (default: the other half minus two)")
     ap.add_argument("--variant", default="video", choices=["video", "raft_config", "successive", "raft", "warp", "api"],
                     help="video / raft_config: BASELINE config 4 with that flow dispatch; raft: BASELINE config 3 as the headline line; "
                          "warp: BASELINE config 2 (VoxelMorph warp of frame pairs); successive: config 4 with the successive.yaml pair of networks; "

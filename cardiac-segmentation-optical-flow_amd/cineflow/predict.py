@@ -40,6 +40,8 @@ from .nifti import read_nifti, write_nifti
 join = os.path.join
 
 MAX_SLICES_PER_LAUNCH = int(os.environ.get("CF_API_SLICES", "64"))   # cropped cine slices per device batch of the file-level API
+FIRST_BATCH_SLICES = int(os.environ.get("CF_API_FIRST_SLICES", "16"))     # slices of the first device batch of a predict_cases / predict_from_folder call
+GIL_SWITCH_INTERVAL = float(os.environ.get("CF_API_SWITCH_INTERVAL", "0.0002"))   # seconds; Python's default is 0.005
 LAST_TIMING = {}                                                     # wall-time split of the last predict_from_folder / predict_cases call
 
 
@@ -629,10 +631,16 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
     """predict.py:228-354 + :1008-1110 for a LIST of patients (`cases[i]` = (list_of_lists, output_filenames, ed_index)): the model is loaded
     once, frames are read and preprocessed by a thread pool one group of patients ahead, every group's cropped slices (up to `max_slices`)
     share one device batch, and finished patients are exported by the NIfTI pool while the next group is on the device."""
+    import sys
     import time
     from collections import deque
     t_start = time.perf_counter()
     max_slices = max_slices or MAX_SLICES_PER_LAUNCH
+    # the calling thread issues ~1500 kernel launches per device batch from Python while up to 32 pool threads read, crop and compress: with
+    # the interpreter's default 5 ms switch interval every hand-over of the GIL to a pool thread could stall the launch stream for
+    # milliseconds (device time of the 16-patient API bench 6.4 -> 10.4 s once preprocessing overlapped fully, profiles/r03_api_split.md)
+    switch_prev = sys.getswitchinterval()
+    sys.setswitchinterval(GIL_SWITCH_INTERVAL)
     trainer, params = _cached_model(model, folds, mixed_precision, checkpoint_name)
     timing = {"load_s": time.perf_counter() - t_start, "preprocess_wait_s": 0.0, "preprocess_work_s": 0.0, "device_s": 0.0, "export_wait_s": 0.0,
               "export_work_s": 0.0, "device_batches": 0, "patients": len(cases), "frames": 0, "slices": 0}
@@ -690,6 +698,9 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
         ahead = 8
         submit_more(ahead)
         carry = None
+        # the first device batch is small (FIRST_BATCH_SLICES) and the cap doubles from batch to batch: the device starts as soon as two
+        # or so patients are read instead of waiting for a full batch of 64 slices, and the later patients are preprocessed behind it
+        cap = min(max_slices, FIRST_BATCH_SLICES)
         while submitted or carry is not None:
             group, nslices = [], 0
             while carry is not None or submitted:
@@ -702,7 +713,7 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
                     carry = (ci, [g[0] for g in got])
                     submit_more(ahead)
                 z = carry[1][0][0].shape[1]
-                if group and nslices + z > max_slices:
+                if group and nslices + z > cap:
                     break
                 group.append(carry)
                 nslices += z
@@ -710,6 +721,7 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
             t0 = time.perf_counter()
             unl = [np.stack([p_[0] for p_ in pre]) + 1e-8 for _ci, pre in group]      # predict.py:1025
             print("predicting %d patient(s), %d slices in one device batch" % (len(group), nslices))
+            cap = min(max_slices, 2 * cap)
             ahead = max(ahead, 2 * len(group) + 2)
             submit_more(ahead)
             # the crop-space copies only when the voxelmorph_saver tree is being written; the `raw` tensor (frames + crop-space flow) the
@@ -741,6 +753,7 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
         pool.close()
         pre_pool.join()
         pool.join()
+        sys.setswitchinterval(switch_prev)
     timing["total_s"] = time.perf_counter() - t_start
     LAST_TIMING.clear()
     LAST_TIMING.update(timing)
