@@ -56,6 +56,11 @@ for (B, C1, C2, H, Cout, act) in CASES:
     x1 = torch.randn(B, C1, H, H, generator=g).to(dev)
     x2 = torch.randn(B, C2, H, H, generator=g).to(dev) if C2 else None
     w = (torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt((C1 + C2) * 9)).to(dev)
+    if os.environ.get("ZERO", "0") != "0":      # power experiment: same instruction stream and memory traffic on all-zero operands
+        x1.zero_()
+        w.zero_()
+        if x2 is not None:
+            x2.zero_()
     wpk, wsc = ops.pack_conv_weight_f16s(w, c1=C1 if (C2 and C1 % 16) else None)
     groups = Cout if act == "lrelu" else 8
     print("B%d C%d+%d %dx%d -> %d" % (B, C1, C2, H, H, Cout))
