@@ -48,7 +48,6 @@ SIGNATURES = {
     "cf_norm_head_1x1": [P, P, F, P, P, P, I, I, I, I, P],
     "cf_conv2d_f16s_prenorm_ok": [I, I, I, I, I],
     "cf_conv_stream_enable": [I],
-    "cf_conv_wreg_enable": [I],
     "cf_conv2d_f16s_prenorm": [P, I, P, F, P, P, P, I, I, I, I, F, P, I, P],
     "cf_group_norm_apply_res_norm": [P, P, P, P, P, I, I, I, I, F, I, I, P, P, P, P, P],
     "cf_group_norm": [P, P, P, P, P, I, I, I, I, F, I, I, P, P],

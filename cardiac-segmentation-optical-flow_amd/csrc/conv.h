@@ -40,9 +40,6 @@ int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s);
 // persistent software-pipelined variant of the f16-split kernel for short-K layers on large maps (conv_stream.hip); the caller zeroes p.gn_ws
 bool conv_stream_applicable(const ConvParams& p);
 int launch_conv_stream(const ConvParams& p, const _Float16* wpk, hipStream_t s);
-// register-resident-weights variant for <= 64 input channels (conv_wreg.hip); conv_stream_applicable / launch_conv_stream route to it
-bool conv_wreg_applicable(const ConvParams& p);
-int launch_conv_wreg(const ConvParams& p, const _Float16* wpk, hipStream_t s);
 
 // RAFT all-pairs volume + pyramid in one kernel (allpairs.hip); returns 1 when the shape is not one it is built for
 int allpairs_pyramid_fused(const float* f1, const float* f2, float* pyr, int B, int C, int H, int W, int levels, hipStream_t stream);

@@ -569,7 +569,6 @@ int stream_enabled() {
 // residual, an even number (>= 2) of 16-channel chunks, image rows that are whole 16-byte quads, enough tiles to keep 256 persistent
 // workgroups busy, one sample of every tensor below 2 GiB; the deferred input normalisation for a single input of <= 341 channels.
 bool conv_stream_applicable(const ConvParams& p) {
-    if (conv_wreg_applicable(p)) return true;      // (<= 64 input channels: the register-resident-weights kernel, its own knob)
     if (!stream_enabled()) return false;
     if (!(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_h == 1 && p.pad_w == 1)) return false;
     if ((p.Cout != 32 && p.Cout != 64) || p.scatter2x2 || p.res || p.act != CF_ACT_NONE || p.out_coff != 0 || p.out_ctotal != p.Cout || p.w_bstride) return false;
@@ -618,7 +617,6 @@ static int launch_stream(const ConvParams& p, const StreamGeom& g, const _Float1
 
 // The caller (conv_f16s.hip) has checked conv_stream_applicable(p) and zeroed p.gn_ws.
 int launch_conv_stream(const ConvParams& p, const _Float16* wpk, hipStream_t s) {
-    if (conv_wreg_applicable(p)) return launch_conv_wreg(p, wpk, s);
     StreamGeom g;
     const int WM = p.Cout <= 32 ? 1 : 2;
     g.tiles_x = (p.W + 31) / 32;

@@ -179,10 +179,6 @@ int cf_norm_head_1x1(const float* x, const float* coef, float slope, const float
  * level 0 routes everything back to conv_f16s (also CF_CONV_STREAM=0), 1 (default) takes the shapes measured faster there (all but the
  * 64-channel layers with deferred input normalisation), 2 every shape the kernel can run.  Returns the previous level. */
 int cf_conv_stream_enable(int on);
-/* Same kind of knob for the register-resident-weights kernel (csrc/conv_wreg.hip: 3x3 / stride 1 layers with <= 64 input channels and 32 or 64
- * output channels on large maps keep their weights in registers for the whole launch; same arithmetic and tap order as the persistent kernel
- * above).  0 routes those layers to the kernels above (also CF_CONV_WREG=0).  Returns the previous setting. */
-int cf_conv_wreg_enable(int on);
 int cf_conv2d_f16s_prenorm_ok(int B, int C, int H, int W, int Cout);
 int cf_conv2d_f16s_prenorm(const float* x, int C, const float* in_norm, float in_slope, const void* wpk, const float* bias, float* out,
                            int B, int H, int W, int Cout, float alpha, double* gn_ws, int gn_groups, void* stream);

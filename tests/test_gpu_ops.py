@@ -949,7 +949,6 @@ def test_conv_stream_matches_conv_f16s(dev, B, C1, C2, H, W, Cout, groups):
     b = randn(Cout, seed=83).to(dev)
     wpk, ws = ops.pack_conv_weight_f16s(w.to(dev), c1=C1 if (C2 and C1 % 16) else None)
     prev = lib().cf_conv_stream_enable(0)
-    prev_w = lib().cf_conv_wreg_enable(0)
     try:
         ref_out, ref_st = ops.conv2d_f16s(x1, wpk, ws, b, Cout, 3, 3, 1, (1, 1), x2=x2, stats_groups=groups)
         ref_plain = ops.conv2d_f16s(x1, wpk, ws, None, Cout, 3, 3, 1, (1, 1), x2=x2)
@@ -959,7 +958,6 @@ def test_conv_stream_matches_conv_f16s(dev, B, C1, C2, H, W, Cout, groups):
         again, st2 = ops.conv2d_f16s(x1, wpk, ws, b, Cout, 3, 3, 1, (1, 1), x2=x2, stats_groups=groups)
     finally:
         lib().cf_conv_stream_enable(prev)
-        lib().cf_conv_wreg_enable(prev_w)
     tol = 4e-6 * (1.0 + float(ref_out.abs().max()))
     assert float((out - ref_out).abs().max()) <= tol and float((plain - ref_plain).abs().max()) <= tol and torch.equal(again, out)
     scale = ref_out.double().abs().view(B, groups, -1).sum(-1)[..., None] + 1.0
@@ -988,7 +986,6 @@ def test_conv_stream_prenorm_matches(dev, B, C, H, W, Cout, act):
     slope = -1.0 if act == "gelu" else 0.01
     og = Cout if act == "lrelu" else 8
     prev = lib().cf_conv_stream_enable(0)
-    prev_w = lib().cf_conv_wreg_enable(0)
     try:
         assert ops.prenorm_ok(raw, Cout)
         ref_out, ref_st = ops.conv2d_f16s_prenorm(raw, coef, slope, wpk, wsc, b, Cout, stats_groups=og)
@@ -997,7 +994,6 @@ def test_conv_stream_prenorm_matches(dev, B, C, H, W, Cout, act):
         out, st = ops.conv2d_f16s_prenorm(raw, coef, slope, wpk, wsc, b, Cout, stats_groups=og)
     finally:
         lib().cf_conv_stream_enable(prev)
-        lib().cf_conv_wreg_enable(prev_w)
     assert float((out - ref_out).abs().max()) <= 4e-6 * (1.0 + float(ref_out.abs().max()))
     scale = ref_out.double().abs().view(B, og, -1).sum(-1)[..., None] + 1.0
     assert float(((st.view(B, og, 2) - ref_st.view(B, og, 2)).abs() / scale).max()) <= 2e-6
@@ -1006,85 +1002,3 @@ def test_conv_stream_prenorm_matches(dev, B, C, H, W, Cout, act):
     xn = F.gelu(xn) if act == "gelu" else F.leaky_relu(xn, 0.01)
     check(out[i:i + 1], F.conv2d(xn, w.cpu().double(), b.cpu().double(), padding=1), 2e-5, "conv_stream prenorm vs fp64")
 
-
-WREG_CASES = [   # B, C1, C2, H, W, Cout, groups
-    (20, 64, 0, 128, 128, 64, 8),      # 64 -> 64: four chunks, two m-tiles (1280 tiles of 8 rows = 5 per workgroup)
-    (24, 32, 0, 128, 128, 64, 8),      # 32 -> 64: two chunks, two m-tiles
-    (32, 32, 0, 128, 128, 32, 32),     # 32 -> 32: two chunks, one m-tile, 16-row tiles (1024 tiles), InstanceNorm statistics
-    (34, 32, 32, 128, 128, 32, 32),    # cat input, four chunks, one m-tile
-    (33, 32, 0, 120, 132, 32, 32),     # ragged rows (120 = 7.5 tiles) and columns
-    (10, 20, 28, 100, 132, 64, 8),     # split-aware packing (C1 = 20 padded to 2 chunks + 28 -> 2 chunks), ragged rows (12.5 tiles) and columns
-    (40, 60, 0, 64, 96, 64, 8),        # zero-weight channel tail (60 of 64), small maps
-    (3, 64, 0, 256, 256, 64, 8),       # 768 tiles: below the threshold -> the knob must change nothing
-]
-
-
-@pytest.mark.parametrize("B,C1,C2,H,W,Cout,groups", WREG_CASES)
-def test_conv_wreg_matches_conv_f16s(dev, B, C1, C2, H, W, Cout, groups):
-    """The register-resident-weights kernel (csrc/conv_wreg.hip) against the one-tile-per-workgroup kernel on the same packed weights: the same
-    3-term products into one fp32 accumulator, taps summed in (kx, ky) order -> equal to fp32 summation-order noise (<= 4e-6 of the output
-    scale), deterministic run to run; fused GroupNorm statistics likewise; one sample against an fp64 convolution."""
-    from cineflow import ops
-    from cineflow._lib import lib
-    x1 = randn(B, C1, H, W, seed=90).to(dev)
-    x2 = randn(B, C2, H, W, seed=91).to(dev) if C2 else None
-    w = randn(Cout, C1 + C2, 3, 3, seed=92) / math.sqrt((C1 + C2) * 9)
-    b = randn(Cout, seed=93).to(dev)
-    wpk, ws = ops.pack_conv_weight_f16s(w.to(dev), c1=C1 if (C2 and C1 % 16) else None)
-    prev = lib().cf_conv_stream_enable(0)
-    prev_w = lib().cf_conv_wreg_enable(0)
-    try:
-        ref_out, ref_st = ops.conv2d_f16s(x1, wpk, ws, b, Cout, 3, 3, 1, (1, 1), x2=x2, stats_groups=groups)
-        ref_plain = ops.conv2d_f16s(x1, wpk, ws, None, Cout, 3, 3, 1, (1, 1), x2=x2)
-        lib().cf_conv_wreg_enable(2)
-        out, st = ops.conv2d_f16s(x1, wpk, ws, b, Cout, 3, 3, 1, (1, 1), x2=x2, stats_groups=groups)
-        plain = ops.conv2d_f16s(x1, wpk, ws, None, Cout, 3, 3, 1, (1, 1), x2=x2)
-        again, st2 = ops.conv2d_f16s(x1, wpk, ws, b, Cout, 3, 3, 1, (1, 1), x2=x2, stats_groups=groups)
-    finally:
-        lib().cf_conv_stream_enable(prev)
-        lib().cf_conv_wreg_enable(prev_w)
-    tol = 4e-6 * (1.0 + float(ref_out.abs().max()))
-    assert float((out - ref_out).abs().max()) <= tol and float((plain - ref_plain).abs().max()) <= tol and torch.equal(again, out)
-    scale = ref_out.double().abs().view(B, groups, -1).sum(-1)[..., None] + 1.0
-    for s_ in (st, st2):
-        assert float(((s_.view(B, groups, 2) - ref_st.view(B, groups, 2)).abs() / scale).max()) <= 2e-6
-    xin = x1[-1:].cpu() if x2 is None else torch.cat([x1[-1:].cpu(), x2[-1:].cpu()], 1)
-    ref = F.conv2d(xin.double(), w.double(), b.cpu().double(), padding=1)
-    check(out[-1:], ref, 1e-5, "conv_wreg vs fp64")
-
-
-@pytest.mark.parametrize("B,C,H,W,Cout,act", [(20, 64, 128, 128, 64, "gelu"), (32, 32, 128, 128, 32, "lrelu"), (24, 32, 128, 128, 64, "gelu"),
-                                              (12, 48, 104, 136, 64, "lrelu")])
-def test_conv_wreg_prenorm_matches(dev, B, C, H, W, Cout, act):
-    """deferred input normalisation in the register-resident-weights kernel: the coefficient table is fetched by LDS-DMA one or two tiles ahead
-    (per-sample statistics differ, consecutive tiles of a workgroup belong to different samples)"""
-    from cineflow import ops
-    from cineflow._lib import lib
-    groups = 8 if act == "gelu" else C
-    raw = (randn(B, C, H, W, seed=94) * (1.0 + 0.2 * torch.arange(B).view(B, 1, 1, 1)) + 0.1 * torch.arange(B).view(B, 1, 1, 1)).to(dev)
-    w = (randn(Cout, C, 3, 3, seed=95) / math.sqrt(9 * C)).to(dev)
-    b = randn(Cout, seed=96).to(dev)
-    gam, bet = (1 + 0.1 * randn(C, seed=97)).to(dev), (0.1 * randn(C, seed=98)).to(dev)
-    wpk, wsc = ops.pack_conv_weight_f16s(w)
-    wsum = torch.stack([raw.double().sum((2, 3)), (raw.double() ** 2).sum((2, 3))], dim=2).view(B, groups, C // groups, 2).sum(2).reshape(-1).contiguous()
-    coef = ops.group_norm_coef(wsum, gam, bet, groups, B, C, H * W)
-    slope = -1.0 if act == "gelu" else 0.01
-    og = Cout if act == "lrelu" else 8
-    prev = lib().cf_conv_stream_enable(0)
-    prev_w = lib().cf_conv_wreg_enable(0)
-    try:
-        assert ops.prenorm_ok(raw, Cout)
-        ref_out, ref_st = ops.conv2d_f16s_prenorm(raw, coef, slope, wpk, wsc, b, Cout, stats_groups=og)
-        lib().cf_conv_wreg_enable(2)
-        assert ops.prenorm_ok(raw, Cout)
-        out, st = ops.conv2d_f16s_prenorm(raw, coef, slope, wpk, wsc, b, Cout, stats_groups=og)
-    finally:
-        lib().cf_conv_stream_enable(prev)
-        lib().cf_conv_wreg_enable(prev_w)
-    assert float((out - ref_out).abs().max()) <= 4e-6 * (1.0 + float(ref_out.abs().max()))
-    scale = ref_out.double().abs().view(B, og, -1).sum(-1)[..., None] + 1.0
-    assert float(((st.view(B, og, 2) - ref_st.view(B, og, 2)).abs() / scale).max()) <= 2e-6
-    i = B - 1
-    xn = F.group_norm(raw[i:i + 1].cpu().double(), groups, gam.cpu().double(), bet.cpu().double(), 1e-5)
-    xn = F.gelu(xn) if act == "gelu" else F.leaky_relu(xn, 0.01)
-    check(out[i:i + 1], F.conv2d(xn, w.cpu().double(), b.cpu().double(), padding=1), 2e-5, "conv_wreg prenorm vs fp64")

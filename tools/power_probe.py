@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Board power and shader clock (rocm-smi, polled from a thread) while one kernel runs back to back for a few seconds: is a layer's time set by the
+power limit?  python tools/power_probe.py   -> one line per workload: average / peak power, average sclk, achieved TF or TB/s."""
+import math
+import os
+import re
+import subprocess
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cardiac-segmentation-optical-flow_amd"))
+import torch  # noqa: E402
+from cineflow import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+samples = []
+stop = False
+
+
+def poll():
+    while not stop:
+        try:
+            o = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+            pw = re.search(r"(?:Average|Current Socket) Graphics Package Power \(W\):\s*([0-9.]+)", o)
+            ck = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", o)
+            samples.append((time.perf_counter(), float(pw.group(1)) if pw else float("nan"), float(ck.group(1)) if ck else float("nan")))
+        except Exception as e:      # noqa: BLE001
+            samples.append((time.perf_counter(), float("nan"), float("nan")))
+        time.sleep(0.2)
+
+
+def run(tag, fn, work, unit, secs=4.0):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < secs:
+        for _ in range(10):
+            fn()
+        n += 10
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    mine = [s for s in samples if t0 + 0.7 <= s[0] <= t1]
+    pw = [s[1] for s in mine if s[1] == s[1]]
+    ck = [s[2] for s in mine if s[2] == s[2]]
+    print("%-44s %7.1f %s | power avg %6.0f W peak %6.0f W (%d samples) | sclk avg %5.0f MHz" % (
+        tag, work * n / (t1 - t0), unit, sum(pw) / max(len(pw), 1), max(pw) if pw else float("nan"), len(pw), sum(ck) / max(len(ck), 1)), flush=True)
+
+
+def conv_case(B, C, H, Cout, zero=False):
+    x = torch.randn(B, C, H, H, generator=g).to(dev)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / math.sqrt(C * 9)).to(dev)
+    if zero:
+        x.zero_()
+        w.zero_()
+    wpk, wsc = ops.pack_conv_weight_f16s(w)
+    return (lambda: ops.conv2d_f16s(x, wpk, wsc, None, Cout, 3, 3, 1, (1, 1), stats_groups=8)), 2.0 * B * H * H * Cout * C * 9 / 1e12
+
+
+th = threading.Thread(target=poll, daemon=True)
+th.start()
+time.sleep(1.5)
+print(subprocess.run(["rocm-smi", "--showmaxpower"], capture_output=True, text=True).stdout.strip().splitlines()[-3:])
+t0 = time.perf_counter()
+time.sleep(2.0)
+idle = [s[1] for s in samples if s[1] == s[1]]
+print("idle: %.0f W" % (sum(idle) / max(len(idle), 1)))
+f, w_ = conv_case(128, 128, 128, 128)
+run("conv 128 -> 128, 128x128, B128 (random)", f, w_, "TF")
+f, w_ = conv_case(128, 128, 128, 128, zero=True)
+run("conv 128 -> 128, 128x128, B128 (zeros)", f, w_, "TF")
+f, w_ = conv_case(128, 64, 256, 64)
+run("conv 64 -> 64, 256x256, B128 (random)", f, w_, "TF")
+f, w_ = conv_case(128, 64, 256, 64, zero=True)
+run("conv 64 -> 64, 256x256, B128 (zeros)", f, w_, "TF")
+x = torch.randn(128, 64, 256, 256, generator=g).to(dev)
+y = torch.empty_like(x)
+run("device copy 2.1 GB (read + write)", lambda: y.copy_(x), 2 * x.numel() * 4 / 1e12, "TB/s")
+gam, bet = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+run("group_norm + GELU apply, 128x64x256x256", lambda: ops.group_norm(x, gam, bet, 8, act="gelu", out=y), 2 * x.numel() * 4 / 1e12, "TB/s")
+stop = True
