@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of the GroupNorm apply pass on the bench's shapes: CF_GN_STREAM=0|1 python tools/gn_apply_ab.py (the knob is read once per process)."""
+"""Bandwidth of the GroupNorm apply pass on the bench's shapes (bytes = x + optional residual + y): python tools/gn_apply_ab.py.
+Round 3: 5.5-6.1 TB/s on every shape (a device copy streams 5.2 TB/s on the same box) -- a streaming variant with compile-time activation,
+four float4 per operand in flight and 64 KB per block measured the same (profiles/r03_gn_apply.txt) and was not kept."""
 import os
 import sys
 
@@ -12,7 +14,6 @@ from microbench import timeit  # noqa: E402
 
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
-print("== CF_GN_STREAM=%s" % os.environ.get("CF_GN_STREAM", "(default)"))
 for (B, C, H, groups, act, with_res) in [(64, 64, 256, 8, "gelu", True), (64, 64, 256, 8, "gelu", False), (64, 128, 128, 8, "gelu", True), (64, 256, 64, 8, "gelu", True),
                                          (240, 32, 256, 32, "lrelu", False), (240, 64, 128, 64, "lrelu", False)]:
     x = torch.randn(B, C, H, H, generator=g).to(dev)
