@@ -439,7 +439,8 @@ __global__ void __launch_bounds__(64 * ST_NW) conv_stream_kernel(const ConvParam
         // cleared one barrier later
         if (ps == 0 && epi) epi_stats_to_global(rp ^ 1, eb2);
         if (ps == 1 && epi && tid < WM * 64) red[(rp ^ 1) * WM * 64 + tid] = 0.f;
-        if (is_c == 0) setup_issue_tile();
+        const bool tab_due = is_c == 0;
+        if (tab_due) setup_issue_tile();
         Epi E;
         if (epi) epi_begin(E);
 #ifdef CF_STREAM_TRACE
@@ -494,7 +495,7 @@ __global__ void __launch_bounds__(64 * ST_NW) conv_stream_kernel(const ConvParam
                         if (dma_unit(k) == u) issue_w1(wchunk, ps ^ 1, k);
                 }
             }
-            if (u == 0) issue_ctab(is_tile & 1);
+            if (u == 0 && tab_due) issue_ctab(is_tile & 1);      // once per tile: with the first chunk of the issue tile (older than that chunk's loads: the counted wait retires it)
             if (u == U_ISSUE) c_issue = issue(st_issue, ok_issue, par_issue);   // unconditional (out-of-range offsets past the last chunk)
             if (u == U_WS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * VT) : "memory");
             if (u >= U_WS && u - U_WS < NSL) write_stage_slice(ps ^ 1, c_write, st_write, ok_write, par_write, (u - U_WS) / 4, (u - U_WS) % 4);
