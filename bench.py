@@ -486,6 +486,9 @@ def bench_api(args, dev, world, rank):
             parallel.barrier()
             dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
         split = {k: round(sum(t[k] for t in tims) / args.steps, 3) for k in ("preprocess_wait_s", "preprocess_work_s", "device_s", "export_wait_s", "export_work_s", "total_s")}
+        for k in ("device_prepare_s", "device_networks_s", "device_finish_s"):       # CF_API_PROFILE=1 only
+            if k in tims[0]:
+                split[k] = round(sum(t[k] for t in tims) / args.steps, 3)
         split["device_batches_per_step"] = tims[0]["device_batches"]
         split["model_load_s_cold"] = round(load_s, 3)
         frames_total = world * npat * Z * T * args.steps

@@ -42,6 +42,24 @@ join = os.path.join
 MAX_SLICES_PER_LAUNCH = int(os.environ.get("CF_API_SLICES", "64"))   # cropped cine slices per device batch of the file-level API
 FIRST_BATCH_SLICES = int(os.environ.get("CF_API_FIRST_SLICES", "16"))     # slices of the first device batch of a predict_cases / predict_from_folder call
 GIL_SWITCH_INTERVAL = float(os.environ.get("CF_API_SWITCH_INTERVAL", "0.0002"))   # seconds; Python's default is 0.005
+_STREAM_POOL = {}                                                    # (device index) -> [torch.cuda.Stream]: reused by the preprocessing threads of every call
+_STREAM_POOL_LOCK = None
+
+
+def _pooled_stream(device, k):
+    global _STREAM_POOL_LOCK
+    import threading
+    if _STREAM_POOL_LOCK is None:
+        _STREAM_POOL_LOCK = threading.Lock()
+    with _STREAM_POOL_LOCK:
+        pool = _STREAM_POOL.setdefault(torch.device(device).index or 0, [])
+        while len(pool) <= k:
+            pool.append(torch.cuda.Stream(device=device))
+        return pool[k]
+
+
+API_PROFILE = os.environ.get("CF_API_PROFILE", "0") != "0"
+DEVICE_SPLIT = {}                                                    # CF_API_PROFILE=1: prepare / networks / finish seconds inside the device batches
 LAST_TIMING = {}                                                     # wall-time split of the last predict_from_folder / predict_cases call
 
 
@@ -288,7 +306,14 @@ class CineTrainer:
         n = len(unlabeled_list)
         targets = targets or [None] * n
         centroids = centroids or [None] * n
+        import time
+        prof = API_PROFILE                                  # CF_API_PROFILE=1: synchronise between the stages and add their times to DEVICE_SPLIT
+        t0 = time.perf_counter()
         preps = [self._flow_prepare(u, t, processor, pad_border_mode, pad_kwargs, c) for u, t, c in zip(unlabeled_list, targets, centroids)]
+        if prof:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            DEVICE_SPLIT["prepare_s"] = DEVICE_SPLIT.get("prepare_s", 0.0) + t1 - t0
         outs = [None] * n
         by_T = {}
         for i, pr in enumerate(preps):
@@ -302,7 +327,15 @@ class CineTrainer:
                 Z = preps[i]["frames"].shape[1]
                 outs[i] = {k: v[:, z0:z0 + Z] for k, v in out.items()}
                 z0 += Z
-        return [self._flow_finish(pr, o, return_crop, want_raw) for pr, o in zip(preps, outs)]
+        if prof:
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            DEVICE_SPLIT["networks_s"] = DEVICE_SPLIT.get("networks_s", 0.0) + t2 - t1
+        res = [self._flow_finish(pr, o, return_crop, want_raw) for pr, o in zip(preps, outs)]
+        if prof:
+            torch.cuda.synchronize()
+            DEVICE_SPLIT["finish_s"] = DEVICE_SPLIT.get("finish_s", 0.0) + time.perf_counter() - t2
+        return res
 
 
 def load_model_and_checkpoint_files(folder, folds=None, mixed_precision=None, checkpoint_name="model_final_checkpoint", device=None):
@@ -662,16 +695,20 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
         T = len(list_of_lists)
         orders.append(list(range(ed_index, T)) + list(range(0, ed_index)))      # ED first (put_ed_first, predict.py:1165-1193)
 
+    import itertools
     import threading
     tls = threading.local()
+    stream_ids = itertools.count()
 
     def pre_one(files):
         # every preprocessing thread issues its (small) device kernels on a HIP stream of its own: on the default stream they -- and the
-        # host read-backs between them -- queued behind the seconds-long network batch of the main thread
+        # host read-backs between them -- queued behind the seconds-long network batch of the main thread.  The streams are taken from a
+        # process-wide pool (thread k of every call gets stream k): torch's caching allocator keeps one pool of blocks per stream, so fresh
+        # streams in every call meant fresh hipMalloc calls -- each a device-wide synchronisation -- under the running network batch
         t0 = time.perf_counter()
         if not hasattr(tls, "stream"):
             torch.cuda.set_device(trainer.device)                                # the current device is per thread (a new thread starts on GPU 0)
-            tls.stream = torch.cuda.Stream(device=trainer.device)
+            tls.stream = _pooled_stream(trainer.device, next(stream_ids))
         with torch.cuda.stream(tls.stream):
             r = trainer.preprocess_patient(files)                                # predict.py:302
             tls.stream.synchronize()
@@ -755,6 +792,9 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
         pool.join()
         sys.setswitchinterval(switch_prev)
     timing["total_s"] = time.perf_counter() - t_start
+    if API_PROFILE:
+        timing.update({"device_" + k: v for k, v in DEVICE_SPLIT.items()})
+        DEVICE_SPLIT.clear()
     LAST_TIMING.clear()
     LAST_TIMING.update(timing)
     return [[(_subfolder_path(o, "Segmentation"), _subfolder_path(o, "Flow")[:-7] + ".npz", _subfolder_path(o, "Registered")) for o in c[1]]
