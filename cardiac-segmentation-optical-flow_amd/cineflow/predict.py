@@ -58,6 +58,10 @@ def _pooled_stream(device, k):
         return pool[k]
 
 
+# "batch" (default): the pool runs one device batch ahead of the collector; "all": the whole request is read and preprocessed before the first
+# batch -- the networks then run at their device-only rate (5.6 instead of 8.1 s for 16 patients) but the reading is not hidden (4.9 s):
+# 310 against 361 frames/s (profiles/r03_api_split.md)
+PREFETCH_ALL = os.environ.get("CF_API_PREFETCH", "batch") == "all"
 API_PROFILE = os.environ.get("CF_API_PROFILE", "0") != "0"
 DEVICE_SPLIT = {}                                                    # CF_API_PROFILE=1: prepare / networks / finish seconds inside the device batches
 LAST_TIMING = {}                                                     # wall-time split of the last predict_from_folder / predict_cases call
@@ -733,11 +737,21 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
         # group are read and cropped while this one is on the device (with 4 the second half of the next group was only submitted after
         # the device batch had finished: 3.4 of 10.5 s of the 16-patient API bench were spent waiting for it, profiles/r03_api_split.md)
         ahead = 8
+        if PREFETCH_ALL:
+            # read and preprocess the WHOLE request before the first device batch: the network kernels run ~35 % longer while the small
+            # preprocessing kernels and their read-backs share the GPU (profiles/r03_api_split.md), and reading is 1-2 s per 16 patients
+            ahead = len(cases)
+            submit_more(ahead)
+            t0 = time.perf_counter()
+            for _ci, asyncs in submitted:
+                for a in asyncs:
+                    a.wait()
+            timing["preprocess_wait_s"] += time.perf_counter() - t0
         submit_more(ahead)
         carry = None
         # the first device batch is small (FIRST_BATCH_SLICES) and the cap doubles from batch to batch: the device starts as soon as two
         # or so patients are read instead of waiting for a full batch of 64 slices, and the later patients are preprocessed behind it
-        cap = min(max_slices, FIRST_BATCH_SLICES)
+        cap = max_slices if PREFETCH_ALL else min(max_slices, FIRST_BATCH_SLICES)
         while submitted or carry is not None:
             group, nslices = [], 0
             while carry is not None or submitted:
