@@ -9,6 +9,7 @@ axes flip sign on the way in and out).
 """
 import gzip
 import struct
+import zlib
 
 import numpy as np
 
@@ -22,17 +23,35 @@ _CODES = {np.dtype(v): k for k, v in _DTYPES.items()}
 GZIP_LEVEL = 2
 
 
+def _gunzip(raw):
+    """All members of a gzip stream, one decompressobj call per member.  Python 3.10's gzip.decompress -- and zlib.decompress with its default
+    16 KB output buffer -- inflate in ~110 small steps and take the GIL back after each: eight reader threads ran one after the other
+    (1.13 s for 80 volumes of 1.8 MB; this form 0.23 s, a single thread 0.13 s per 10)."""
+    out = []
+    while raw:
+        d = zlib.decompressobj(wbits=31)
+        out.append(d.decompress(raw))
+        if not d.eof:
+            raise ValueError("truncated gzip stream")
+        raw = d.unused_data.lstrip(b"\0")          # (zero padding between / after members is legal)
+    return out[0] if len(out) == 1 else b"".join(out)
+
+
+def _gzip(data, level):
+    """gzip container in one zlib call (gzip.compress goes through GzipFile.write and scales 2.2x on 8 threads, this 6.5x)"""
+    c = zlib.compressobj(level, zlib.DEFLATED, 31)
+    return c.compress(data) + c.flush()
+
+
 def _read_all(path):
-    """whole file in, ONE decompress call: the gzip module's buffered reader made ~220 small GIL-holding calls per 2 MB volume, which with 16
-    reader threads turned 25 ms of inflate into 0.27 s per frame (profiles/r03_api_split.md)"""
     with open(path, "rb") as f:
         raw = f.read()
-    return gzip.decompress(raw) if str(path).endswith(".gz") else raw
+    return _gunzip(raw) if str(path).endswith(".gz") else raw
 
 
 def _write_all(path, data):
     with open(path, "wb") as f:
-        f.write(gzip.compress(data, compresslevel=GZIP_LEVEL) if str(path).endswith(".gz") else data)
+        f.write(_gzip(data, GZIP_LEVEL) if str(path).endswith(".gz") else data)
 
 
 def write_nifti(path, array, spacing=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), direction=(1, 0, 0, 0, 1, 0, 0, 0, 1)):

@@ -62,6 +62,42 @@ def _pooled_stream(device, k):
 # batch -- the networks then run at their device-only rate (5.6 instead of 8.1 s for 16 patients) but the reading is not hidden (4.9 s):
 # 310 against 361 frames/s (profiles/r03_api_split.md)
 PREFETCH_ALL = os.environ.get("CF_API_PREFETCH", "batch") == "all"
+class _StackSampler:
+    """CF_API_PROFILE=2: every 2 ms the innermost three frames of all other threads (sys._current_frames), as a histogram on stderr"""
+
+    def __init__(self):
+        import collections
+        import threading
+        self.hist, self.stop, self.me = collections.Counter(), False, threading.get_ident()
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        import sys
+        import threading
+        import time
+        own = threading.get_ident()
+        while not self.stop:
+            for tid, f in sys._current_frames().items():
+                if tid in (own, self.me):
+                    continue
+                chain = []
+                while f is not None and len(chain) < 3:
+                    chain.append("%s:%d %s" % (os.path.basename(f.f_code.co_filename), f.f_lineno, f.f_code.co_name))
+                    f = f.f_back
+                self.hist[" <- ".join(chain)] += 1
+            time.sleep(0.002)
+
+    def report(self, title):
+        import sys
+        self.stop = True
+        self.t.join()
+        tot = sum(self.hist.values())
+        print("== " + title, file=sys.stderr)
+        for k, v in self.hist.most_common(16):
+            print("   %5.1f %%  %s" % (100.0 * v / max(tot, 1), k[:220]), file=sys.stderr)
+
+
 API_PROFILE = os.environ.get("CF_API_PROFILE", "0") != "0"
 DEVICE_SPLIT = {}                                                    # CF_API_PROFILE=1: prepare / networks / finish seconds inside the device batches
 LAST_TIMING = {}                                                     # wall-time split of the last predict_from_folder / predict_cases call
@@ -743,9 +779,12 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
             ahead = len(cases)
             submit_more(ahead)
             t0 = time.perf_counter()
+            sampler = _StackSampler() if os.environ.get("CF_API_PROFILE", "0") == "2" else None
             for _ci, asyncs in submitted:
                 for a in asyncs:
                     a.wait()
+            if sampler:
+                sampler.report("preprocessing threads while the request is read (%.2f s)" % (time.perf_counter() - t0))
             timing["preprocess_wait_s"] += time.perf_counter() - t0
         submit_more(ahead)
         carry = None
