@@ -81,5 +81,19 @@ try:
 
     one_run(1)
     one_run(nthreads)
+    if len(sys.argv) > 3:           # third argument: also after the full-size networks have been loaded and have run one batch in this process
+        import bench
+        from cineflow.inference import predict_cine_slices
+        fnet, snet = bench.load_nets(bench.make_nets("video"), dev, 1234, 1, 0)
+        frames = bench.synthetic_cine(int(sys.argv[3]), 30, 256, 1234).to(dev)
+        ed = bench.ring_labels(int(sys.argv[3]), 256).to(dev)
+        bench.run_step(fnet, snet, frames, ed)
+        torch.cuda.synchronize()
+        print("-- after loading the networks and one batch of %s slices (allocator: %.1f GiB reserved)" % (sys.argv[3], torch.cuda.memory_reserved() / 2**30))
+        one_run(nthreads)
+        del frames, ed
+        torch.cuda.empty_cache()
+        print("-- after torch.cuda.empty_cache() (%.1f GiB reserved)" % (torch.cuda.memory_reserved() / 2**30))
+        one_run(nthreads)
 finally:
     shutil.rmtree(root, ignore_errors=True)
