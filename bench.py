@@ -51,7 +51,7 @@ MFMA_F16_SUSTAINED_TFLOPS = 1720.0
 # HBM bytes per launch over algorithmic bytes, from the separate PMC passes (FETCH_SIZE / WRITE_SIZE with the guide's wide-load correction):
 # the live line carries `traffic` = algorithmic x this ratio with its source, it cannot collect counters itself (gpurun refuses --pmc next to
 # tracing, and a PMC pass serialises kernels).
-PMC_TRAFFIC_RATIO = {"conv_f16s": (1.00, "profiles/r02_pmc_hbm_traffic.md (reads 1.00-1.03x, writes 1.00x algorithmic)"),
+PMC_TRAFFIC_RATIO = {"conv_f16s": (1.00, "profiles/r02_pmc_hbm_traffic.md, r03_pmc_hbm_traffic.md (reads 1.00-1.03x, writes 1.00x algorithmic)"),
                      "corr": (1.18, "profiles/r01_pmc_hbm_traffic.md, re-measured in profiles/r03_pmc_hbm_traffic.md (reads 1.28-1.33x at dilation 4, 1.02x at dilation 1, writes exact; byte-weighted 1.18x)")}
 
 
