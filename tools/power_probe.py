@@ -68,17 +68,29 @@ t0 = time.perf_counter()
 time.sleep(2.0)
 idle = [s[1] for s in samples if s[1] == s[1]]
 print("idle: %.0f W" % (sum(idle) / max(len(idle), 1)))
+only_corr = len(sys.argv) > 1 and sys.argv[1] == "corr"
 f, w_ = conv_case(128, 128, 128, 128)
-run("conv 128 -> 128, 128x128, B128 (random)", f, w_, "TF")
-f, w_ = conv_case(128, 128, 128, 128, zero=True)
-run("conv 128 -> 128, 128x128, B128 (zeros)", f, w_, "TF")
-f, w_ = conv_case(128, 64, 256, 64)
-run("conv 64 -> 64, 256x256, B128 (random)", f, w_, "TF")
-f, w_ = conv_case(128, 64, 256, 64, zero=True)
-run("conv 64 -> 64, 256x256, B128 (zeros)", f, w_, "TF")
-x = torch.randn(128, 64, 256, 256, generator=g).to(dev)
-y = torch.empty_like(x)
-run("device copy 2.1 GB (read + write)", lambda: y.copy_(x), 2 * x.numel() * 4 / 1e12, "TB/s")
-gam, bet = torch.ones(64, device=dev), torch.zeros(64, device=dev)
-run("group_norm + GELU apply, 128x64x256x256", lambda: ops.group_norm(x, gam, bet, 8, act="gelu", out=y), 2 * x.numel() * 4 / 1e12, "TB/s")
+run("conv 128 -> 128, 128x128, B128 (random)", f, w_, "TF", secs=1.5 if only_corr else 4.0)
+if not only_corr:
+    f, w_ = conv_case(128, 128, 128, 128, zero=True)
+    run("conv 128 -> 128, 128x128, B128 (zeros)", f, w_, "TF")
+    f, w_ = conv_case(128, 64, 256, 64)
+    run("conv 64 -> 64, 256x256, B128 (random)", f, w_, "TF")
+    f, w_ = conv_case(128, 64, 256, 64, zero=True)
+    run("conv 64 -> 64, 256x256, B128 (zeros)", f, w_, "TF")
+    x = torch.randn(128, 64, 256, 256, generator=g).to(dev)
+    y = torch.empty_like(x)
+    run("device copy 2.1 GB (read + write)", lambda: y.copy_(x), 2 * x.numel() * 4 / 1e12, "TB/s")
+    gam, bet = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    run("group_norm + GELU apply, 128x64x256x256", lambda: ops.group_norm(x, gam, bet, 8, act="gelu", out=y), 2 * x.numel() * 4 / 1e12, "TB/s")
+if len(sys.argv) > 1 and sys.argv[1] == "corr":
+    for (C, H, st) in [(64, 256, 4), (128, 128, 2), (256, 64, 1)]:
+        a = torch.randn(128, C, H, H, generator=g).to(dev)
+        b = torch.randn(128, C, H, H, generator=g).to(dev)
+        run("corr_volume C=%d %dx%d dilation %d, B=128" % (C, H, H, st), lambda: ops.corr_volume(a, b, 4, st), 4.0 * 128 * H * H * (2 * C + 81) / 1e12, "TB/s")
+        a.zero_()
+        b.zero_()
+        run("   the same on zeros", lambda: ops.corr_volume(a, b, 4, st), 4.0 * 128 * H * H * (2 * C + 81) / 1e12, "TB/s")
+        del a, b
+        torch.cuda.empty_cache()
 stop = True
