@@ -713,7 +713,6 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
     # the interpreter's default 5 ms switch interval every hand-over of the GIL to a pool thread could stall the launch stream for
     # milliseconds (device time of the 16-patient API bench 6.4 -> 10.4 s once preprocessing overlapped fully, profiles/r03_api_split.md)
     switch_prev = sys.getswitchinterval()
-    sys.setswitchinterval(GIL_SWITCH_INTERVAL)
     trainer, params = _cached_model(model, folds, mixed_precision, checkpoint_name)
     timing = {"load_s": time.perf_counter() - t_start, "preprocess_wait_s": 0.0, "preprocess_work_s": 0.0, "device_s": 0.0, "export_wait_s": 0.0,
               "export_work_s": 0.0, "device_batches": 0, "patients": len(cases), "frames": 0, "slices": 0}
@@ -767,6 +766,7 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
             nxt += 1
 
     finishing = deque()                                                          # exports in flight: (seg_paths, reg_paths, jobs, output files)
+    sys.setswitchinterval(GIL_SWITCH_INTERVAL)                                   # restored in the finally below
     try:
         # slices of a patient are only known after preprocessing; groups are filled greedily in patient order.  The pool runs `ahead` patients
         # in front of the collector: at least one whole device batch more than the group being assembled, so that the frames of the NEXT
