@@ -26,7 +26,7 @@ try:
     g = torch.Generator().manual_seed(0)
     files = []
     for i in range(nthreads * per):
-        a = (torch.rand(8, 256, 216, generator=g).numpy() * 60.0 + 200.0).astype(np.float32)
+        a = (torch.rand(8, 256, 256, generator=g).numpy() * 60.0 + 200.0).astype(np.float32)
         f = os.path.join(root, "f%04d_0000.nii.gz" % i)
         write_nifti(f, a, (1.25, 1.25, 10.0))
         files.append([f])
@@ -81,6 +81,32 @@ try:
 
     one_run(1)
     one_run(nthreads)
+    # the same frames through multiprocessing.pool.ThreadPool.apply_async, as cineflow.predict._predict_patients submits them
+    from multiprocessing.pool import ThreadPool
+    tls = threading.local()
+
+    def pre_one(fl):
+        if not hasattr(tls, "st"):
+            torch.cuda.set_device(dev)
+            tls.st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(tls.st):
+            r = trainer.preprocess_patient(fl)
+            tls.st.synchronize()
+        return r
+    for keep in (False, True):
+        pool = ThreadPool(nthreads)
+        t0 = time.perf_counter()
+        res = [pool.apply_async(pre_one, (f,)) for f in files]
+        out = []
+        for a in res:
+            r = a.get()
+            if keep:
+                out.append(r)
+        dt = time.perf_counter() - t0
+        pool.close()
+        pool.join()
+        print("== ThreadPool(%d).apply_async x %d frames, results %s: %.2f s wall, %.1f ms wall per frame" % (nthreads, len(files), "kept" if keep else "dropped", dt, dt / len(files) * 1e3))
+        del out
     if len(sys.argv) > 3:           # third argument: also after the full-size networks have been loaded and have run one batch in this process
         import bench
         from cineflow.inference import predict_cine_slices
