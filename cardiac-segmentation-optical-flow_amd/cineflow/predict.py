@@ -230,9 +230,7 @@ class CineTrainer:
         if stages:
             st = stages[str(plans.get("stage", 0))] if isinstance(stages, dict) and str(plans.get("stage", 0)) in stages else stages[plans.get("stage", 0)]
             return pre.preprocess_test_case(list(input_files), np.array(st["current_spacing"], dtype=float))
-        data, seg, properties = P.ImageCropper.crop_from_list_of_files(list(input_files))
-        own = np.array(properties["original_spacing"], dtype=float)[list(plans["transpose_forward"])]
-        return pre.preprocess_arrays(data, seg, properties, own)
+        return pre.preprocess_test_case(list(input_files), None)      # (no stages in the plans: the case keeps its own spacing)
 
     # -- nnUNetTrainer.py:637-679
     def predict_preprocessed_data_return_seg_and_softmax(self, data, do_mirroring=True, mirror_axes=None, use_sliding_window=True,

@@ -126,7 +126,7 @@ class ImageCropper(object):
     def crop(data, properties, seg=None):
         data, seg, bbox = crop_to_nonzero(data, seg, nonzero_label=-1)
         properties["crop_bbox"] = bbox
-        properties["classes"] = np.unique(seg.cpu().numpy() if torch.is_tensor(seg) else seg)
+        properties["classes"] = torch.unique(seg).cpu().numpy() if torch.is_tensor(seg) else np.unique(seg)
         seg[seg < -1] = 0
         properties["size_after_cropping"] = tuple(data[0].shape)
         return data, seg, properties
@@ -346,10 +346,19 @@ class GenericPreprocessor(object):
 
     _remove_nans = True
 
-    def preprocess_test_case(self, data_files, target_spacing, seg_file=None, force_separate_z=None):
-        """preprocessing.py:323-331 -> (data float32 [C, ...], seg, properties), numpy like the reference."""
-        data, seg, properties = ImageCropper.crop_from_list_of_files(data_files, seg_file)
-        return self.preprocess_arrays(data, seg, properties, target_spacing, force_separate_z)
+    def preprocess_test_case(self, data_files, target_spacing=None, seg_file=None, force_separate_z=None, need_seg=True):
+        """preprocessing.py:323-331 -> (data float32 [C, ...], seg, properties), numpy like the reference.  The case goes to the device once
+        and comes back once: crop, transpose, resampling and normalisation hand device tensors to each other (the numpy-in / numpy-out
+        functions above cost two more 2 MB copies and a 4 MB int64 label map per frame, with a stream synchronisation each, which the
+        file-level API paid under a running network batch -- profiles/r03_api_split.md).  need_seg=False skips the label map's read-back."""
+        data, seg, properties = load_case_from_list_of_files(data_files, seg_file)
+        data, seg, properties = ImageCropper.crop(_to_dev(data), properties, None if seg is None else _to_dev(seg))
+        tf = (0, *[i + 1 for i in self.transpose_forward])
+        if target_spacing is None:        # (plans without stages: the case keeps its own spacing)
+            target_spacing = np.array(properties["original_spacing"], dtype=float)[list(self.transpose_forward)]
+        d, s, properties = self.resample_and_normalize(data.permute(tf).contiguous(), target_spacing, properties, seg.permute(tf).contiguous(),
+                                                       force_separate_z=force_separate_z)
+        return d.cpu().numpy().astype(np.float32, copy=False), (s.cpu().numpy() if need_seg else None), properties
 
     def preprocess_arrays(self, data, seg, properties, target_spacing, force_separate_z=None):
         tf = (0, *[i + 1 for i in self.transpose_forward])
