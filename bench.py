@@ -457,8 +457,8 @@ def bench_api(args, dev, world, rank):
         threads = host_threads()
         # pool sizes of the call (the reference's num_threads_preprocessing / num_threads_nifti_save); the calling thread needs a core of
         # its own for the launch stream, so the two pools share the rest
-        pre_threads = args.pre_threads or max(1, threads // 2)
-        save_threads = args.save_threads or max(1, threads - pre_threads - 2)
+        pre_threads = args.pre_threads or max(1, threads // 4)                       # measured on a 16-thread box: 4 + 10 > 6 + 8 > 8 + 6 (reading is light since the
+        save_threads = args.save_threads or max(1, threads - pre_threads - 2)        # case makes one device round trip; the export compresses three files per frame)
 
         def call(tag, n):
             out = os.path.join(root, "out_" + tag)
@@ -543,8 +543,8 @@ def main():
     ap.add_argument("--frames", type=int, default=30, help="frames per cine slice (T)")
     ap.add_argument("--pairs", type=int, default=None, help="frame pairs per step and per GPU (default: 128 for raft, 960 for warp)")
     ap.add_argument("--patients", type=int, default=16, help="api variant: synthetic patients (8 slices each) per step and per GPU")
-    ap.add_argument("--pre-threads", type=int, default=0, help="api variant: num_threads_preprocessing (default: half the host threads)")
-    ap.add_argument("--save-threads", type=int, default=0, help="api variant: num_threads_nifti_save (default: the other half minus two)")
+    ap.add_argument("--pre-threads", type=int, default=0, help="api variant: num_threads_preprocessing (default: a quarter of the host threads)")
+    ap.add_argument("--save-threads", type=int, default=0, help="api variant: num_threads_nifti_save (default: the rest minus two)")
     ap.add_argument("--variant", default="video", choices=["video", "raft_config", "successive", "raft", "warp", "api"],
                     help="video / raft_config: BASELINE config 4 with that flow dispatch; raft: BASELINE config 3 as the headline line; "
                          "warp: BASELINE config 2 (VoxelMorph warp of frame pairs); successive: config 4 with the successive.yaml pair of networks; "
