@@ -152,3 +152,31 @@ def test_preprocess_test_case_files(dev, golden, tmp_path):
     assert float(np.abs(d - od).max()) <= 2e-5 and np.array_equal(s, os_)
     assert props["crop_bbox"] == op["crop_bbox"] and tuple(props["size_after_cropping"]) == tuple(op["size_after_cropping"])
     assert np.allclose(props["original_spacing"], np.array(spacing_xyz)[::-1]) and list(props["classes"]) == [-1, 0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tf", [[0, 1, 2], [2, 0, 1]])
+def test_preprocess_test_case_one_round_trip_equals_function_chain(dev, golden, tmp_path, tf):
+    """preprocess_test_case keeps the case on the device between crop, transpose, resampling and normalisation; the reference-shaped numpy-in /
+    numpy-out functions (crop_from_list_of_files -> preprocess_arrays) go through the host between them: same kernels, so identical arrays"""
+    from cineflow import preprocessing as P
+    from cineflow.nifti import write_nifti
+    g = golden("preprocess_crop")
+    files = []
+    for c in range(2):
+        f = str(tmp_path / ("case_%04d.nii.gz" % c))
+        write_nifti(f, g["data"][c], spacing=(1.5625, 1.5625, 10.0))
+        files.append(f)
+    pre = P.GenericPreprocessor({0: "nonCT", 1: "nonCT"}, {0: False, 1: True}, tf)
+    target = np.array([5.0, 1.25, 1.25])[tf] if tf != [0, 1, 2] else np.array([10.0, 1.25, 1.25])
+    d1, s1, p1 = pre.preprocess_test_case(files, target)
+    data, seg, props = P.ImageCropper.crop_from_list_of_files(files)
+    d2, s2, p2 = pre.preprocess_arrays(data, seg, props, target)
+    assert d1.dtype == d2.dtype == np.float32 and np.array_equal(d1, d2) and np.array_equal(s1, s2)
+    for k in ("crop_bbox", "size_after_cropping", "size_after_resampling"):
+        assert tuple(map(tuple, p1[k])) == tuple(map(tuple, p2[k])) if k == "crop_bbox" else tuple(p1[k]) == tuple(p2[k])
+    assert list(p1["classes"]) == list(p2["classes"])
+    d3, s3, _ = pre.preprocess_test_case(files, target, need_seg=False)
+    assert s3 is None and np.array_equal(d3, d1)
+    d4, _, _ = pre.preprocess_test_case(files)          # no target spacing: the case keeps its own
+    assert d4.shape[1:] == tuple(np.array(p1["size_after_cropping"])[tf])
