@@ -293,7 +293,7 @@ class CineTrainer:
         return [h.numpy() for h in hosts]
 
     # -- :3427-3467 after the network call: per-slice uncrop, centre window, un-pad, host copies
-    def _flow_finish(self, prep, out, return_crop, want_raw=True):
+    def _flow_finish(self, prep, out, return_crop, want_raw=True, want_softmax=True):
         T, Z, Y, X, Hp, Wp, y1, y2, x1, x2 = prep["geom"]
         processor, pad_need, slicer, frames, dev = prep["processor"], prep["pad_need"], prep["slicer"], prep["frames"], self.device
 
@@ -308,12 +308,15 @@ class CineTrainer:
         flow = place(out["flow"].permute(0, 2, 1, 3, 4).contiguous())                  # [T,2,Z,Y,X]
         reg = place(out["registered"].float())[:, None]                                # [T,1,Z,Y,X]
         seg = ops.argmax_channels(softmax.reshape(T, self.num_classes, -1).contiguous()).view(T, Z, Y, X)
-        dev_out = [seg, softmax.contiguous(), flow.contiguous(), reg.contiguous()]
+        # (want_softmax=False: the exporter will write the device arg-max `seg`; the [T,K,Z,Y,X] probabilities -- 200 MB per patient -- stay on the device)
+        dev_out = [seg, softmax.contiguous() if want_softmax else torch.empty(0, device=dev), flow.contiguous(), reg.contiguous()]
         if want_raw:
             dev_out.append(torch.cat([frames.permute(0, 2, 1, 3, 4), out["flow"].permute(0, 2, 1, 3, 4)], 1))
         if return_crop:
             dev_out += [out["softmax"].permute(0, 2, 1, 3, 4).contiguous(), out["flow"].permute(0, 2, 1, 3, 4).contiguous(), out["registered"].contiguous()]
         host = self._to_host(dev_out)
+        if not want_softmax:
+            host[1] = None
         res = tuple(host[:4]) + ((host[4],) if want_raw else (None,))
         if return_crop:
             c = host[-3:]
@@ -333,7 +336,7 @@ class CineTrainer:
                                           pad_border_mode=pad_border_mode, pad_kwargs=pad_kwargs, centroids=[centroid], return_crop=return_crop)[0]
 
     def predict_patients_flow(self, unlabeled_list, targets=None, processor=None, do_mirroring=True, mirror_axes=None, pad_border_mode="constant",
-                              pad_kwargs=None, centroids=None, return_crop=False, want_raw=True):
+                              pad_kwargs=None, centroids=None, return_crop=False, want_raw=True, want_softmax=True):
         """The one-patient call above for several patients whose cropped slices share ONE device batch: every patient is padded / cropped /
         z-scored on its own (`_flow_prepare`), the `[T, Z_p, 1, c, c]` stacks of the patients with the same frame count T are concatenated
         on the slice axis, predict_cine_slices runs once per such group, and each patient's slices go back through its own un-crop
@@ -369,7 +372,7 @@ class CineTrainer:
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             DEVICE_SPLIT["networks_s"] = DEVICE_SPLIT.get("networks_s", 0.0) + t2 - t1
-        res = [self._flow_finish(pr, o, return_crop, want_raw) for pr, o in zip(preps, outs)]
+        res = [self._flow_finish(pr, o, return_crop, want_raw, want_softmax) for pr, o in zip(preps, outs)]
         if prof:
             torch.cuda.synchronize()
             DEVICE_SPLIT["finish_s"] = DEVICE_SPLIT.get("finish_s", 0.0) + time.perf_counter() - t2
@@ -410,7 +413,7 @@ def get_lowres_axis(new_spacing):
 def save_segmentation_nifti_from_softmax(segmentation_softmax, out_fname, properties_dict, order=1, region_class_order=None,
                                          seg_postprogess_fn=None, seg_postprocess_args=None, resampled_npz_fname=None,
                                          non_postprocessed_fname=None, force_separate_z=None, interpolation_order_z=0, verbose=True,
-                                         flow=None, flow_path=None, registered=None, registered_path=None):
+                                         flow=None, flow_path=None, registered=None, registered_path=None, seg_precomputed=None):
     """segmentation_export.py:29-223: resample softmax / flow / registered labels back to the size before resampling (device
     kernels, cineflow.ops.resample_data_or_seg), rescale the flow to the new pixel grid, argmax, place into the crop bounding
     box, write uint8 NIfTI with the case's geometry; flow [2,Z,Y,X] -> npz `flow` [Y,X,Z,2] float32 + `spacing`."""
@@ -419,8 +422,15 @@ def save_segmentation_nifti_from_softmax(segmentation_softmax, out_fname, proper
         del_file = segmentation_softmax
         segmentation_softmax = np.load(segmentation_softmax)
         os.remove(del_file)
-    current_shape = segmentation_softmax.shape
     shape_after_crop = tuple(properties_dict.get("size_after_cropping"))
+    if seg_precomputed is not None:
+        # the caller already holds arg-max(softmax) at the size after cropping (computed on the device, first maximum like numpy) and needs
+        # neither the resampling branch nor the npz: the probabilities never left the device
+        assert segmentation_softmax is None and resampled_npz_fname is None and region_class_order is None
+        assert tuple(seg_precomputed.shape) == shape_after_crop, "seg_precomputed must have the size after cropping"
+        current_shape = (0,) + tuple(seg_precomputed.shape)
+    else:
+        current_shape = segmentation_softmax.shape
     shape_before_crop = properties_dict.get("original_size_of_raw_data")
     if any(i != j for i, j in zip(current_shape[1:], shape_after_crop)):
         if force_separate_z is None:                                             # segmentation_export.py:88-98
@@ -455,7 +465,9 @@ def save_segmentation_nifti_from_softmax(segmentation_softmax, out_fname, proper
         seg_old_spacing = segmentation_softmax
     if resampled_npz_fname is not None:
         np.savez_compressed(resampled_npz_fname, softmax=seg_old_spacing.astype(np.float16))
-    if region_class_order is None:
+    if seg_precomputed is not None:
+        seg = np.asarray(seg_precomputed)
+    elif region_class_order is None:
         seg = seg_old_spacing.argmax(0)
     else:
         seg = np.zeros(seg_old_spacing.shape[1:])
@@ -587,7 +599,8 @@ def _export_flow_patient(result, trainer, output_filenames, property_list, inter
     voxelmorph_raw = _VOXELMORPH_RAW
     seg, softmax, flow, registered, _raw = result[:5]
     crop_out = result[5] if len(result) > 5 else None
-    assert len(softmax) == len(flow) == len(registered)
+    have_softmax = softmax is not None          # None: no resampling and no npz asked for -> the frames are written from the device arg-max `seg`
+    assert len(seg) == len(flow) == len(registered) and (not have_softmax or len(softmax) == len(flow))
     if voxelmorph_raw is not None:
         assert crop_out is not None, "set_voxelmorph_raw was switched on after the device stage of this patient"
         from .voxelmorph_saver import write_raw
@@ -597,18 +610,22 @@ def _export_flow_patient(result, trainer, output_filenames, property_list, inter
     # back to the axis order of the files (predict.py:1084-1089): preprocessing applied plans['transpose_forward']
     if trainer.plans.get("transpose_forward") is not None:
         tb = [0] + [i + 1 for i in trainer.plans.get("transpose_backward")]
-        softmax = [np.ascontiguousarray(x.transpose(tb)) for x in softmax]
+        if have_softmax:
+            softmax = [np.ascontiguousarray(x.transpose(tb)) for x in softmax]
+        else:
+            seg = [np.ascontiguousarray(x.transpose(trainer.plans.get("transpose_backward"))) for x in seg]
         flow = [np.ascontiguousarray(x.transpose(tb)) for x in flow]
         registered = [np.ascontiguousarray(x.transpose(tb)) for x in registered]
     seg_paths, flow_paths, reg_paths, jobs = [], [], [], []
-    for t in range(len(softmax)):
+    for t in range(len(flow)):
         seg_path, flow_path, reg_path = (_subfolder_path(output_filenames[t], s_) for s_ in ("Segmentation", "Flow", "Registered"))
         seg_paths.append(seg_path)
         flow_paths.append(flow_path[:-7] + ".npz")
         reg_paths.append(reg_path)
         npz = seg_path[:-7] + ".npz" if save_npz else None
-        jobs.append(pool.apply_async(_timed_export, (trainer.device, softmax[t], seg_path, property_list[t], interpolation_order, None, None, None, npz, None,
-                                                     force_separate_z, interpolation_order_z, False, flow[t], flow_paths[-1], registered[t], reg_path)))
+        jobs.append(pool.apply_async(_timed_export, (trainer.device, softmax[t] if have_softmax else None, seg_path, property_list[t], interpolation_order, None,
+                                                     None, None, npz, None, force_separate_z, interpolation_order_z, False, flow[t], flow_paths[-1],
+                                                     registered[t], reg_path, None if have_softmax else seg[t])))
     return seg_paths, flow_paths, reg_paths, jobs
 
 
@@ -814,8 +831,12 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
             submit_more(ahead)
             # the crop-space copies only when the voxelmorph_saver tree is being written; the `raw` tensor (frames + crop-space flow) the
             # reference returns for its trainer's plots is not consumed by the exporter
+            # the probabilities come to the host only if the exporter needs them: for the npz, or to resample them back to the size
+            # before the preprocessing's resampling (segmentation_export.py:84-127); otherwise it writes the device arg-max
+            tf_ = list(trainer.plans["transpose_forward"])
+            resampled = any(tuple(p_[0].shape[1:]) != tuple(np.array(p_[2]["size_after_cropping"])[tf_]) for _ci, pre in group for p_ in pre)
             results = trainer.predict_patients_flow(unl, do_mirroring=do_tta, mirror_axes=trainer.data_aug_params["mirror_axes"],
-                                                    return_crop=_VOXELMORPH_RAW is not None, want_raw=False)
+                                                    return_crop=_VOXELMORPH_RAW is not None, want_raw=False, want_softmax=bool(save_npz or resampled))
             torch.cuda.synchronize()
             timing["device_s"] += time.perf_counter() - t0
             timing["device_batches"] += 1

@@ -608,6 +608,43 @@ def test_predict_from_folder_batches_slices_across_patients(dev, tmp_path):
 
 
 @pytest.mark.gpu
+def test_export_from_device_argmax_equals_export_from_softmax(dev, tmp_path):
+    """save_npz=False and no resampling: the exporter writes the device arg-max and the [T,K,Z,Y,X] probabilities never come to the host;
+    save_npz=True takes the reference's route (softmax to the host, argmax there).  Same launches, so the files must be identical."""
+    from cineflow import predict as P
+    from cineflow.models import SegFlowGaussian, Generic_UNet
+    from cineflow.nifti import read_nifti, write_nifti
+    from cineflow.weights import seeded_state_dict
+    red = dict(in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=32, bottleneck_heads=4, dim_feedforward=48)
+    plans = P.default_plans(image_size=64, crop_size=64, flow_variant="video", seg_base=8, seg_pool=3, reduced=red)
+    plans["transpose_forward"], plans["transpose_backward"] = [0, 2, 1], [0, 2, 1]
+    seg = Generic_UNet(1, 8, 4, 3)
+    flow = SegFlowGaussian(image_size=64, motion_appearance=False, **red)
+    model = str(tmp_path / "model")
+    P.save_model_folder(model, seg, flow, plans, fold=0, seg_sd=seeded_state_dict(seg.state_shapes(), 20),
+                        flow_sd=seeded_state_dict({k: v for k, v in flow.state_shapes().items() if not k.endswith("grid")}, 21))
+    inp = tmp_path / "in"
+    g = torch.Generator().manual_seed(7)
+    (inp / "patient001").mkdir(parents=True)
+    T, Z = 4, 3
+    for t in range(T):
+        vol = torch.randn(Z, 56, 64, generator=g).numpy().astype(np.float32) * 40 + 100
+        write_nifti(str(inp / "patient001" / ("patient001_frame%02d_0000.nii.gz" % t)), vol, (1.5, 1.5, 8.0), (0, 0, 0))
+    P.predict_from_folder(model, str(inp), str(tmp_path / "seg"), [0], False, 2, 2, None, 0, 1, True)
+    P.predict_from_folder(model, str(inp), str(tmp_path / "soft"), [0], True, 2, 2, None, 0, 1, True)
+    for t in range(T):
+        case = "patient001_frame%02d" % t
+        a, pa = read_nifti(str(tmp_path / "seg" / "patient001" / "Segmentation" / (case + ".nii.gz")))
+        b, pb = read_nifti(str(tmp_path / "soft" / "patient001" / "Segmentation" / (case + ".nii.gz")))
+        assert a.shape == (Z, 56, 64) and a.dtype == b.dtype and np.array_equal(a, b) and pa == pb
+        assert os.path.isfile(str(tmp_path / "soft" / "patient001" / "Segmentation" / (case + ".npz")))
+        assert not os.path.isfile(str(tmp_path / "seg" / "patient001" / "Segmentation" / (case + ".npz")))
+        fa = np.load(str(tmp_path / "seg" / "patient001" / "Flow" / (case + ".npz")))["flow"]
+        fb = np.load(str(tmp_path / "soft" / "patient001" / "Flow" / (case + ".npz")))["flow"]
+        assert float(np.abs(fa - fb).max()) <= 1e-5          # (two runs of the networks: the fused statistics' atomics meet in a different order)
+
+
+@pytest.mark.gpu
 def test_trainer_built_from_successive_config_vs_oracle(dev):
     """plans['flow_net'] = {'config': <successive.yaml values>}: cineflow.config builds ModelWrap(model1, model2) and the trainer drives it
     through the flow-network interface (ED -> t cumulative flow); values against the oracle's ModelWrap on the same seeded weights."""
