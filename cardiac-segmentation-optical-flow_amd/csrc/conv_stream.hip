@@ -228,17 +228,22 @@ __global__ void __launch_bounds__(64 * ST_NW) conv_stream_kernel(const ConvParam
     };
     // One slice = the four channels of image column k of staging task t: conversion + two 8-byte LDS writes.  The slices of a chunk are spread
     // over the tap units of the step before the one that multiplies it (in the MFMA shadow); write_stage = all of them at once (prologue).
+    // PRE: the {mean, scale, shift} quads of a task's four channels, read from the table with the task's FIRST slice and kept for its other three
+    // (three ds_read_b128 per task and chunk instead of twelve)
+    f32x4v pcm[VT], pca[VT], pcs[VT];
+#pragma unroll
+    for (int t = 0; t < VT; ++t) pcm[t] = pca[t] = pcs[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
     auto write_stage_slice = [&](int slot, int chunk, const f32x4v (&stg)[VT][4], const bool (&ok)[VT], int par, const int t, const int k)
                                  __attribute__((always_inline)) {
         unsigned char* base = patch + slot * PATCH + v_lds[t];
-        f32x4v cm = {0.f, 0.f, 0.f, 0.f}, ca = cm, cs = cm;
-        if (PRE) {
+        if (PRE && k == 0) {
             const float* ct = ctab + par * CT_SLOT;
             const int c0 = chunk * CK + (int)v_c4[t];
-            cm = *reinterpret_cast<const f32x4v*>(ct + c0);
-            ca = *reinterpret_cast<const f32x4v*>(ct + ctab_n + c0);
-            cs = *reinterpret_cast<const f32x4v*>(ct + 2 * ctab_n + c0);
+            pcm[t] = *reinterpret_cast<const f32x4v*>(ct + c0);
+            pca[t] = *reinterpret_cast<const f32x4v*>(ct + ctab_n + c0);
+            pcs[t] = *reinterpret_cast<const f32x4v*>(ct + 2 * ctab_n + c0);
         }
+        const f32x4v cm = pcm[t], ca = pca[t], cs = pcs[t];
         // every loaded register is consumed UNCONDITIONALLY (conversion of all four columns), only the LDS writes of columns outside the
         // patch are masked: a load whose only uses sit behind a branch stays "maybe pending" for the compiler's wait insertion, which
         // then fences every later reuse of that register with a vmcnt wait that drains the chunks in flight
