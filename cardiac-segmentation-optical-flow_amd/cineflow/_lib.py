@@ -49,6 +49,10 @@ SIGNATURES = {
     "cf_conv2d_f16s_prenorm_ok": [I, I, I, I, I],
     "cf_conv_stream_enable": [I],
     "cf_conv2d_f16s_prenorm": [P, I, P, F, P, P, P, I, I, I, I, F, P, I, P],
+    "cf_conv_wino_enable": [I],
+    "cf_conv2d_wino_ok": [I, I, I, I, I, I, I],
+    "cf_conv2d_wino": [P, I, P, I, P, P, P, P, I, I, I, I, I, I, I, F, P, I, P],
+    "cf_conv2d_wino_prenorm": [P, I, P, F, P, P, P, I, I, I, I, F, P, I, P],
     "cf_group_norm_apply_res_norm": [P, P, P, P, P, I, I, I, I, F, I, I, P, P, P, P, P],
     "cf_group_norm": [P, P, P, P, P, I, I, I, I, F, I, I, P, P],
     "cf_layer_norm_cf": [P, P, P, P, I, I, I, F, P],

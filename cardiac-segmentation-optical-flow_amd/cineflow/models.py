@@ -456,14 +456,12 @@ class StackedConvLayers(Module):
                 raw, ws, norm = pending
                 B, C, H, W = raw.shape
                 coef = ops.group_norm_coef(ws, norm._p["weight"], norm._p["bias"], norm.groups, B, C, H * W, norm.eps)
-                y, ws_b = ops.conv2d_f16s_prenorm(raw, coef, 0.01, b.conv._wpk, b.conv._ws, b.conv._p.get("bias"), b.conv.cout,
-                                                  stats_groups=b.instnorm.groups)
+                y, ws_b = b.conv.prenorm(raw, coef, 0.01, stats_groups=b.instnorm.groups)
             else:
                 kw = {} if (x2 is None or i > 0) else {"x2": x2}
                 y, ws_b = b.conv(x, stats_groups=b.instnorm.groups, **kw)
             nxt = defer_last if last else self.blocks[i + 1].conv
-            if (nxt is not None and ws_b is not None and nxt.ks == (3, 3) and nxt.stride == 1 and getattr(nxt, "sub", None) is None
-                    and getattr(nxt, "_f16s", False) and ops.prenorm_ok(y, nxt.cout)):
+            if nxt is not None and ws_b is not None and ops.CONV_MODE == "f16s" and nxt.ks == (3, 3) and nxt.prenorm_ok(y):
                 pending = (y, ws_b, b.instnorm)
                 continue
             if last and nxt is not None and ws_b is not None and nxt.ks == (1, 1) and nxt.stride == 1 and ops.norm_head_ok(y, nxt.cout):

@@ -103,6 +103,33 @@ class Conv2d(Module):
             if self._f16s:
                 self._wpk, self._ws = ops.pack_conv_weight_f16s(self._p["weight"])
                 self._wpk_split = {}
+            # 3x3 / stride 1 layers with whole 128-channel output blocks (or a last block >= 96) may take the row-Winograd kernel
+            # (ops.wino_ok decides per call shape); its weights are transformed and packed on first use
+            self._wino = (self._f16s and self.ks == (3, 3) and self.stride == 1 and self.pad == (1, 1) and self.sub is None
+                          and (self.cout % 128 == 0 or (self.cout > 128 and self.cout % 128 >= 96)))
+            self._wino_pk = {}
+
+    def _packed_wino(self, c1, split):
+        key = c1 if (split and c1 % 16) else None
+        if key not in self._wino_pk:
+            self._wino_pk[key] = ops.pack_conv_weight_wino(self._p["weight"], c1=key)
+        return self._wino_pk[key]
+
+    def prenorm_ok(self, x):
+        """can this convolution take the RAW convolution output x with its normalisation + activation deferred (applied while the tile is
+        staged)?  3x3 / stride 1 only; on the Winograd kernel where that takes the shape, else on conv_f16s' vector-staging shapes"""
+        if not (self.ks == (3, 3) and self.stride == 1 and self.sub is None and getattr(self, "_f16s", False) and ops.PRENORM and x.data_ptr() % 16 == 0):
+            return False
+        B, C, H, W = x.shape
+        return (self._wino and ops.wino_ok(B, C, 0, H, W, self.cout, prenorm=True)) or ops.prenorm_ok(x, self.cout)
+
+    def prenorm(self, x, coef, slope, stats_groups=None):
+        """conv(act((x - mean) * scale + shift)) with coef from ops.group_norm_coef; slope < 0: GELU.  Caller checked prenorm_ok(x)."""
+        B, C, H, W = x.shape
+        if self._wino and ops.wino_ok(B, C, 0, H, W, self.cout, prenorm=True):
+            wpk, wsc = self._packed_wino(C, False)
+            return ops.conv2d_wino_prenorm(x, coef, slope, wpk, wsc, self._p.get("bias"), self.cout, stats_groups=stats_groups)
+        return ops.conv2d_f16s_prenorm(x, coef, slope, self._wpk, self._ws, self._p.get("bias"), self.cout, stats_groups=stats_groups)
 
     def _packed(self, x, x2):
         """packed weights for this call's channel split (cat[x, x2] with x.shape[1] not a chunk multiple: packed once per split)"""
@@ -133,6 +160,11 @@ class Conv2d(Module):
         Wo = (x.shape[3] + 2 * self.pad[1] - self.ks[1]) // self.stride + 1
         if self._f16s and ops.CONV_MODE == "f16s" and ops.f16s_dynamic_ok(x, x2, self.ks[0], out_sample_elems=(self.cout if out is None else out.shape[1]) * Ho * Wo,
                                                                            out_hw=Ho * Wo):
+            if (self._wino and x.data_ptr() % 16 == 0 and (x2 is None or x2.data_ptr() % 16 == 0)
+                    and ops.wino_ok(x.shape[0], x.shape[1], 0 if x2 is None else x2.shape[1], x.shape[2], x.shape[3], self.cout)):
+                wpk, wsc = self._packed_wino(x.shape[1], x2 is not None)
+                return ops.conv2d_wino(x, wpk, wsc, self._p.get("bias"), self.cout, x2=x2, act=act, res=res, out=out, out_coff=out_coff,
+                                       stats_groups=stats_groups)
             wpk, wsc = self._packed(x, x2)
             return ops.conv2d_f16s(x, wpk, wsc, self._p.get("bias"), self.cout, self.ks[0], self.ks[1], self.stride, self.pad,
                                    x2=x2, act=act, res=res, out=out, out_coff=out_coff, stats_groups=stats_groups)
@@ -371,14 +403,12 @@ class DoubleConv(Module):
         """conv2 on GELU(GN1(t_raw)) with the normalisation applied while conv2 stages its input -> (raw conv2 output, its statistics)"""
         B, C, H, W = t_raw.shape
         coef = ops.group_norm_coef(ws1, self.norm1._p["weight"], self.norm1._p["bias"], self.norm1.groups, B, C, H * W, self.norm1.eps)
-        return ops.conv2d_f16s_prenorm(t_raw, coef, -1.0, self.conv2._wpk, self.conv2._ws, self.conv2._p.get("bias"), self.conv2.cout,
-                                       stats_groups=self.norm2.groups)
+        return self.conv2.prenorm(t_raw, coef, -1.0, stats_groups=self.norm2.groups)
 
     def forward(self, x, x2=None):
         kw1 = {} if x2 is None else {"x2": x2}
         t, ws1 = self.conv1(x, stats_groups=self.norm1.groups, **kw1)
-        pre = (PRENORM_GELU and ws1 is not None and self.conv2.ks == (3, 3) and self.conv2.stride == 1 and getattr(self.conv2, "_f16s", False)
-               and ops.prenorm_ok(t, self.conv2.cout))
+        pre = PRENORM_GELU and ws1 is not None and ops.CONV_MODE == "f16s" and self.conv2.prenorm_ok(t)
         if pre:
             y2, ws2 = self._conv2(t, ws1)
             conv2 = lambda **k: self.norm2(y2, act="gelu", ws=ws2, **k)                       # noqa: E731

@@ -221,6 +221,82 @@ def pack_conv_weight_f16s(w, c1=None):
     return x.view(-1), s
 
 
+# ---- row Winograd F(2,3) form of the same convolution (conv_wino.hip) ----------------------------------------------------
+WINO = os.environ.get("CF_CONV_WINO", "1") != "0"         # 0: every layer stays on the direct kernels (A/B knob; the library reads it too)
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))      # G of F(2,3): U = G g along kx
+
+
+def wino_ok(B, C1, C2, H, W, cout, prenorm=False):
+    """does cf_conv2d_wino take this 3x3 / stride 1 / pad 1 layer?  (Cout in whole 128-channel blocks or a last block >= 96, W % 16 == 0,
+    H a multiple of the tile rows)"""
+    return bool(WINO and CONV_MODE == "f16s" and lib().cf_conv2d_wino_ok(B, C1, C2, H, W, cout, 1 if prenorm else 0) == 1)
+
+
+def pack_conv_weight_wino(w, c1=None):
+    """torch conv weight [Cout,Cin,3,3] -> (packed fp16 tensor, scale exponent s) for cf_conv2d_wino.
+
+    U[co][ci][ky][pos] = sum_kx G[pos][kx] w[co][ci][ky][kx] in fp64 (G = the F(2,3) kernel transform), scaled by 2^s (max|U| -> ~2^10),
+    rounded to fp32 and split into fp16 hi / lo.  Fragment order [m-tile][chunk][step = ky * 4 + pos][part hi/lo][lane = h*32 + r][j]:
+    value = 2^s * U[mt*32 + r][chunk*16 + 8h + j][ky][pos]; m-tiles padded to whole 128-channel blocks, channels to 16; c1 as in
+    pack_conv_weight_f16s (cat[x1, x2] with x1's channels padded to whole chunks)."""
+    import math
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) == (3, 3)
+    G = torch.tensor(_WINO_G, dtype=torch.float64, device=w.device)
+    U = torch.einsum("pk,ocyk->ocyp", G, w.to(torch.float64)).reshape(cout, cin, 12)
+    umax = float(U.abs().max())
+    s = int(math.floor(math.log2(1024.0 / umax))) if umax > 0 else 0
+    s = max(-24, min(24, s))
+    us = (U * (2.0 ** s)).to(torch.float32)
+    ck = 16
+    nmt = 4 * ((cout + 127) // 128)
+    if c1 is not None and 0 < c1 < cin and c1 % ck:
+        c1p = (c1 + ck - 1) // ck * ck
+        nchunk = c1p // ck + (cin - c1 + ck - 1) // ck
+        wp = torch.zeros((nmt * 32, nchunk * ck, 12), dtype=torch.float32, device=w.device)
+        wp[:cout, :c1] = us[:, :c1]
+        wp[:cout, c1p:c1p + cin - c1] = us[:, c1:]
+    else:
+        nchunk = (cin + ck - 1) // ck
+        wp = torch.zeros((nmt * 32, nchunk * ck, 12), dtype=torch.float32, device=w.device)
+        wp[:cout, :cin] = us
+    hi = wp.half()
+    lo = (wp - hi.float()).half()
+    x = torch.stack([hi, lo])                                  # [part, co, ci, step]
+    x = x.view(2, nmt, 32, nchunk, 2, 8, 12)                   # part, mt, r, chunk, h, j, step
+    x = x.permute(1, 3, 6, 0, 4, 2, 5).contiguous()           # mt, chunk, step, part, h, r, j
+    return x.view(-1), s
+
+
+def conv2d_wino(x1, wpk, wscale, bias, cout, x2=None, act=None, res=None, out=None, out_coff=0, alpha=1.0, stats_groups=None):
+    """cf_conv2d_wino: 3x3 / stride 1 / pad 1; arguments and returns as conv2d_f16s (wpk from pack_conv_weight_wino)."""
+    B, C1, H, W = x1.shape
+    C2 = 0 if x2 is None else x2.shape[1]
+    if out is None:
+        out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x1.device)
+    assert out.shape[0] == B and out.shape[2] == H and out.shape[3] == W
+    if res is not None:
+        assert res.shape == (B, cout, H, W)
+    assert wpk.dtype == torch.float16 and wpk.is_cuda
+    if F16S_RANGE_CHECK:
+        _range_check(x1, x2)
+    ws = _zeroed_stats_ws(2 * B * stats_groups, x1.device) if stats_groups else None
+    check(lib().cf_conv2d_wino(_f32(x1), C1, _opt(x2), C2, wpk.data_ptr(), _opt(bias), _opt(res), _f32(out), out.shape[1], out_coff, B, H, W,
+                               cout, ACT[act], float(alpha) * (2.0 ** -wscale), None if ws is None else ws.data_ptr(),
+                               -stats_groups if stats_groups else 0, _stream()), "cf_conv2d_wino")
+    return (out, ws) if stats_groups else out
+
+
+def conv2d_wino_prenorm(x, coef, slope, wpk, wscale, bias, cout, stats_groups=None):
+    """cf_conv2d_wino_prenorm: as conv2d_f16s_prenorm on the Winograd kernel."""
+    B, C, H, W = x.shape
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    ws = _zeroed_stats_ws(2 * B * stats_groups, x.device) if stats_groups else None
+    check(lib().cf_conv2d_wino_prenorm(_f32(x), C, _f32(coef), float(slope), wpk.data_ptr(), _opt(bias), _f32(out), B, H, W, cout, 2.0 ** -wscale,
+                                       None if ws is None else ws.data_ptr(), -stats_groups if stats_groups else 0, _stream()), "cf_conv2d_wino_prenorm")
+    return (out, ws) if stats_groups else out
+
+
 # CF_F16S_RANGE_CHECK=1 (debug): every input of an f16-split convolution is scanned for values the hi/lo split cannot carry (non-finite or
 # |x| >= 65504, e.g. a `noNorm` modality fed to a network without an input normalisation); f16s_range_violations() returns the count so far.
 # Such values come out of the kernel as NaN by design; the exact route for them is set_conv_mode("f32").

@@ -23,9 +23,15 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # CF_DIST_BACKEND=gloo: several ranks on ONE GPU (the 2-rank GPU test of the product API on a 1-GPU box; RCCL refuses two ranks
+            # on one device)
+            backend = os.environ.get("CF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        # CF_DIST_DEVICE_ID=0 falls back to the lazy communicator initialisation of rounds 1-2 (no device_id): the eager path has only
+        # ever run with one rank on hardware, so a failure at scale can be bisected in a single run
+        if backend == "nccl" and os.environ.get("CF_DIST_DEVICE_ID", "1") != "0":
             # bind this rank to ITS GPU before the process group exists and tell the group so: without device_id the first collective opens
             # a lazy context on device 0 from every rank (memory and time lost on GPU 0 of an 8-rank job).  Every GPU stays visible to every
             # rank -- RCCL's xGMI peer paths need that -- so no *_VISIBLE_DEVICES masking here.

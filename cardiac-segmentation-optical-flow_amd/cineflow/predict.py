@@ -23,6 +23,7 @@ Differences that are deliberate and documented in DESIGN.md:
 """
 import argparse
 import csv
+import glob
 import json
 import os
 import shutil
@@ -379,20 +380,74 @@ class CineTrainer:
         return res
 
 
+def _fold_dirs(folder, folds):
+    if folds is None or folds == "None":
+        return sorted(d for d in os.listdir(folder) if d.startswith("fold_"))
+    if isinstance(folds, (list, tuple)):
+        return ["fold_%s" % i if str(i) != "all" else "all" for i in folds]
+    return ["fold_%s" % folds]
+
+
+_CHECKPOINT_PARTS = (("seg_state_dict", "seg_net"), ("flow_state_dict", "flow_net"), ("crop_state_dict", "crop_net"))
+
+
+def _broadcast_params(trainer, params, nfolds, device):
+    """The one collective of the multi-GPU path (the reference has no hook: every `--part_id` process of
+    predict.py:806-821 reads the checkpoint itself): rank 0 holds `params` (the folds' checkpoint dicts), every rank gets each fold's weights
+    as ONE flat fp32 broadcast (RCCL over xGMI under the nccl backend, gloo on CPU tensors) and rebuilds the dicts `load_checkpoint_ram` takes.
+    Shapes come from the networks every rank built from plans.json, so ranks >= 1 need no checkpoint file."""
+    from . import parallel
+    shapes = {}
+    for key, attr in _CHECKPOINT_PARTS:
+        net = getattr(trainer, attr, None)
+        if net is not None:
+            for k, v in net.state_shapes().items():
+                if not k.endswith("grid"):                                       # SpatialTransformer grids are rebuilt, never loaded
+                    shapes[key + "/" + k] = v
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    out = []
+    for f in range(nfolds):
+        flat = None
+        if rank == 0:
+            flat = {}
+            for key, _ in _CHECKPOINT_PARTS:
+                for k, v in (params[f].get(key) or {}).items():
+                    if key + "/" + k in shapes:
+                        flat[key + "/" + k] = v
+            missing = sorted(set(shapes) - set(flat))
+            if missing:
+                raise KeyError("checkpoint lacks %d tensors the networks of plans.json need, e.g. %s" % (len(missing), missing[:3]))
+        got = parallel.broadcast_state_dict(flat, shapes, device)
+        p = {}
+        for name, t in got.items():
+            key, k = name.split("/", 1)
+            p.setdefault(key, {})[k] = t
+        out.append(p)
+    return out
+
+
 def load_model_and_checkpoint_files(folder, folds=None, mixed_precision=None, checkpoint_name="model_final_checkpoint", device=None):
-    """model_restore.py:109-155 equivalent for the plans.json / *.model folder format -> (trainer, [params per fold])."""
+    """model_restore.py:109-155 equivalent for the plans.json / *.model folder format -> (trainer, [params per fold]).
+    In a multi-process job (WORLD_SIZE > 1, one process per GPU) only rank 0 reads `fold_X/<checkpoint_name>.model`; the other ranks need
+    plans.json alone and receive the weights through cineflow.parallel.broadcast_state_dict before the patient loop."""
     assert os.path.isfile(join(folder, "plans.json")), "Folder with saved model weights must contain a plans.json file"
     with open(join(folder, "plans.json")) as f:
         plans = json.load(f)
-    if folds is None or folds == "None":
-        folds = sorted(d for d in os.listdir(folder) if d.startswith("fold_"))
-    elif isinstance(folds, (list, tuple)):
-        folds = ["fold_%s" % i if str(i) != "all" else "all" for i in folds]
-    else:
-        folds = ["fold_%s" % folds]
     device = device or torch.device("cuda", torch.cuda.current_device())
     trainer = CineTrainer(plans, device, model_folder=folder)
-    params = [torch.load(join(folder, f, checkpoint_name + ".model"), map_location="cpu", weights_only=True) for f in folds]
+    trainer.mixed_precision = bool(mixed_precision)
+    from . import parallel
+    rank, world, _ = parallel.init_from_env()
+    if world > 1:
+        import torch.distributed as dist
+        fold_dirs = _fold_dirs(folder, folds) if rank == 0 else None
+        n = torch.tensor([len(fold_dirs) if rank == 0 else 0], dtype=torch.int64, device=device if device.type == "cuda" else "cpu")
+        dist.broadcast(n, src=0)
+        params = ([torch.load(join(folder, f, checkpoint_name + ".model"), map_location="cpu", weights_only=True) for f in fold_dirs]
+                  if rank == 0 else None)
+        return trainer, _broadcast_params(trainer, params, int(n.item()), device)
+    params = [torch.load(join(folder, f, checkpoint_name + ".model"), map_location="cpu", weights_only=True) for f in _fold_dirs(folder, folds)]
     return trainer, params
 
 
@@ -699,11 +754,41 @@ def predict_non_flow(d, trainer, output_filenames, property_list, do_tta, mixed_
 _MODEL_CACHE = {}
 
 
+def clear_model_cache():
+    """drop the resident model of `_cached_model` (the next predict_* call reads plans.json and the checkpoint again)"""
+    _MODEL_CACHE.clear()
+
+
+def _file_stamp(path):
+    try:
+        st = os.stat(path)
+        return (st.st_mtime_ns, st.st_size)
+    except OSError:
+        return None
+
+
+def _model_stamp(model, folds, checkpoint_name):
+    """(mtime_ns, size) of plans.json, of every selected fold's <checkpoint_name>.model and of the config files plans.json may name: a
+    checkpoint rewritten in place (same plans) must not be served from the cache.  Ranks without checkpoint files stamp what they have."""
+    stamp = [_file_stamp(join(model, "plans.json"))]
+    try:
+        fold_dirs = _fold_dirs(model, folds)
+    except OSError:
+        fold_dirs = []
+    for f in fold_dirs:
+        stamp.append((f, _file_stamp(join(model, f, checkpoint_name + ".model"))))
+    for extra in sorted(glob.glob(join(model, "*.yaml"))):
+        stamp.append((os.path.basename(extra), _file_stamp(extra)))
+    return tuple(stamp)
+
+
 def _cached_model(model, folds, mixed_precision, checkpoint_name):
-    """load_model_and_checkpoint_files + load_checkpoint_ram once per (folder, folds, checkpoint, file time): predict_from_folder used to
-    rebuild both networks and re-read the checkpoint for every patient"""
-    key = (os.path.abspath(model), str(folds), checkpoint_name, torch.cuda.current_device())
-    stamp = os.path.getmtime(join(model, "plans.json"))
+    """load_model_and_checkpoint_files + load_checkpoint_ram once per (folder, folds, checkpoint, mixed_precision, device, the CF_* knobs in
+    force) and per state of the files on disk (`_model_stamp`): predict_from_folder used to rebuild both networks and re-read the checkpoint
+    for every patient.  The reference re-reads the checkpoint on every predict_cases call; `clear_model_cache()` forces that here."""
+    knobs = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("CF_")))
+    key = (os.path.abspath(model), str(folds), checkpoint_name, bool(mixed_precision), torch.cuda.current_device(), knobs)
+    stamp = _model_stamp(model, folds, checkpoint_name)
     hit = _MODEL_CACHE.get(key)
     if hit is None or hit[0] != stamp:
         _MODEL_CACHE.clear()                                                     # one model resident at a time
@@ -857,8 +942,13 @@ def _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, 
             sp, rp, jobs, outs = finishing.popleft()
             timing["export_work_s"] += _finish_flow_patient(sp, rp, jobs, outs, disable_postprocessing, model)
         timing["export_wait_s"] += time.perf_counter() - t0
+    except BaseException:
+        # a failed batch must not wait for every queued preprocessing / export job: drop them
+        pre_pool.terminate()
+        pool.terminate()
+        raise
     finally:
-        pre_pool.close()
+        pre_pool.close()                                                         # (no-ops after terminate())
         pool.close()
         pre_pool.join()
         pool.join()
@@ -921,6 +1011,11 @@ def predict_from_folder(model, input_folder, output_folder, folds, save_npz, num
     if mode not in ("normal", "fast", "fastest"):
         raise ValueError("unrecognized mode. Must be normal, fast or fastest")
     patients = sorted(p for p in os.listdir(input_folder) if os.path.isdir(join(input_folder, p)))
+    # one process per GPU under torchrun (RANK / WORLD_SIZE): the reference's partition with part_id = rank, num_parts = world unless the
+    # caller partitions explicitly (predict.py:743, :806-821)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and num_parts == 1:
+        part_id, num_parts = int(os.environ.get("RANK", "0")), world
     shard, cases = patients[part_id::num_parts], []
     for patient in shard:
         current_input_folder = join(input_folder, patient)
@@ -942,6 +1037,8 @@ def predict_from_folder(model, input_folder, output_folder, folds, save_npz, num
         assert save_npz is False                                                 # predict.py:755, :771
     if mode == "fastest":                                                        # predict.py:504-626: nearest-neighbour export
         seg_exp = {"force_separate_z": None, "interpolation_order": 0, "interpolation_order_z": 0}
+    if not cases and world > 1:
+        _cached_model(model, folds, mixed_precision, checkpoint_name)            # an empty shard still takes part in the weight broadcast
     res = _predict_patients(model, cases, folds, save_npz, num_threads_preprocessing, num_threads_nifti_save, tta, mixed_precision,
                             bool(overwrite_all_in_gpu), step_size, checkpoint_name, seg_exp, disable_postprocessing) if cases else []
     return dict(zip(shard, res))

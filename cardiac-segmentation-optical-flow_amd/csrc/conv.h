@@ -41,6 +41,11 @@ int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s);
 bool conv_stream_applicable(const ConvParams& p);
 int launch_conv_stream(const ConvParams& p, const _Float16* wpk, hipStream_t s);
 
+// row Winograd F(2,3) form of the f16-split kernel for 3x3 / stride 1 layers with >= 128 output channels (conv_wino.hip); `wpk` is packed
+// by cineflow.ops.pack_conv_weight_wino (NOT the direct kernels' packing)
+bool conv_wino_applicable(const ConvParams& p);
+int launch_conv_wino(const ConvParams& p, const _Float16* wpk, hipStream_t s);
+
 // RAFT all-pairs volume + pyramid in one kernel (allpairs.hip); returns 1 when the shape is not one it is built for
 int allpairs_pyramid_fused(const float* f1, const float* f2, float* pyr, int B, int C, int H, int W, int levels, hipStream_t stream);
 

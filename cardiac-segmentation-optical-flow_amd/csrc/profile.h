@@ -19,7 +19,8 @@ enum ProfileKernel {
     PK_WARP = 11, PK_WARP_LABELS = 12, PK_JACOBIAN = 13,     // VoxelMorph warp family (2-D); work = algorithmic bytes
     PK_CONV_SMALL_COUT = 14,                                 // direct 3x3 convolution to <= 4 output channels (flow heads); work = algorithmic bytes
     PK_CONV_STREAM = 15,                                     // conv_stream_kernel (same arithmetic as PK_CONV_F16S); work = flops
-    PK_COUNT = 16
+    PK_CONV_WINO = 16,                                       // conv_wino_kernel (row Winograd F(2,3), 3-term split); work = direct-form flops
+    PK_COUNT = 17
 };
 
 bool profile_on();

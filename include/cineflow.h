@@ -183,6 +183,27 @@ int cf_conv2d_f16s_prenorm_ok(int B, int C, int H, int W, int Cout);
 int cf_conv2d_f16s_prenorm(const float* x, int C, const float* in_norm, float in_slope, const void* wpk, const float* bias, float* out,
                            int B, int H, int W, int Cout, float alpha, double* gn_ws, int gn_groups, void* stream);
 
+/* The same operator (nn.Conv2d 3x3 / stride 1 / padding 1 of DoubleConv, nnunet/lib/utils.py:1182-1215; ConvDropoutNormNonlin,
+ * generic_UNet.py:26-69; ConvGRUCell's gate convolutions, convGRU.py:57-66) as a ROW Winograd F(2,3) on the f16 MFMA with the 3-term hi/lo
+ * split (csrc/conv_wino.hip): the input transform (d0 - d2, d1 + d2, d2 - d1, d1 - d3) runs in fp32 before the split, the kernel transform
+ * (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2) on the host in fp64 (cineflow/ops.py pack_conv_weight_wino -- `wpk` is NOT the
+ * direct kernels' packing), 12 instead of 18 MFMA k-steps per pair of output columns; results equal cf_conv2d_f16s' to fp32 summation
+ * noise (3-5e-7 of max|y| against fp64 at 128 / 256 channels).  Built for Cout in whole 128-channel blocks (or a last block >= 96: the
+ * U-Net's 480), W % 16 == 0, H a multiple of the tile rows (4 / 8 at W >= 32, 8 / 16 at W = 16), 16-byte aligned inputs, one sample of
+ * each tensor < 2 GiB; arguments as cf_conv2d_f16s (cat[x1, x2] packed split-aware when C1 % 16 != 0; alpha carries 2^-s; fused GroupNorm
+ * statistics with gn_ws), the _prenorm form as cf_conv2d_f16s_prenorm.  cf_conv2d_wino_ok(B, C1, C2, H, W, Cout, prenorm) returns 1 when
+ * a shape qualifies (no launch); the calls fail with CF_ERR_ARG otherwise (the caller stays on cf_conv2d_f16s).  CF_CONV_WINO=0 in the
+ * environment makes cf_conv2d_wino_ok answer 0 for every shape (A/B knob). */
+int cf_conv2d_wino_ok(int B, int C1, int C2, int H, int W, int Cout, int prenorm);
+/* route level (tests, A/B runs): 0 = off, 1 = automatic workgroup shape (default), 2 / 4 = force 2 / 4 unit tiles per wave where the geometry
+ * allows (initial value from CF_CONV_WINO and CF_WINO_NTW).  Returns the previous level. */
+int cf_conv_wino_enable(int level);
+int cf_conv2d_wino(const float* x1, int C1, const float* x2, int C2, const void* wpk, const float* bias, const float* res, float* out,
+                   int out_ctotal, int out_coff, int B, int H, int W, int Cout, int act, float alpha, double* gn_ws, int gn_groups,
+                   void* stream);
+int cf_conv2d_wino_prenorm(const float* x, int C, const float* in_norm, float in_slope, const void* wpk, const float* bias, float* out,
+                           int B, int H, int W, int Cout, float alpha, double* gn_ws, int gn_groups, void* stream);
+
 /* nn.LayerNorm(C) over the channel axis of channel-first tokens x [B,C,N] (lib/vit_transformer.py:1257,1261,1265);
  * the residual add is done by the preceding conv epilogue. */
 int cf_layer_norm_cf(const float* x, const float* gamma, const float* beta, float* out, int B, int C, int N, float eps,
@@ -356,7 +377,7 @@ int cf_sample_points_2d(const float* field, const float* pts, float* out, int B,
  * 0,1,2 = conv_igemm MT 1,2,4 (work = flops); 3,4,5 = corr_volume_p7 stride 1,2,4 (work = algorithmic bytes);
  * 6 = conv_f16s (work = flops); 7 = RAFT all-pairs volume + pyramid pooling, 8 = RAFT correlation lookup, 9 = convex
  * upsampling, 10 = GroupNorm apply passes, 11 = 2-D bilinear warp, 12 = 2-D label warp, 13 = 2-D Jacobian determinant (work =
- * algorithmic bytes).
+ * algorithmic bytes), 14 = direct 3x3 convolution to <= 4 channels (bytes), 15 = conv_stream, 16 = conv_wino (work = direct-form flops).
  * cf_profile_read sums kernel durations [ms], work and launches since the last cf_profile_reset (it synchronises: call it
  * outside the timed region). */
 int cf_profile_enable(int max_launches);

@@ -126,3 +126,62 @@ def test_bench_successive_and_api_variants_dry_run():
         assert r.returncode == 0, r.stderr[-2000:]
         d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
         assert d["config"]["variant"] == variant and d["weights_identical_on_all_ranks"] is True
+
+
+def _api_worker(rank, world, port, q, folders):
+    """cineflow.predict.load_model_and_checkpoint_files in a 2-rank job: rank 1's model folder holds plans.json ONLY"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "cardiac-segmentation-optical-flow_amd"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from cineflow import parallel, predict
+    parallel.init_from_env(backend="gloo")
+    trainer, params = predict.load_model_and_checkpoint_files(folders[rank], folds=None, mixed_precision=True, device=torch.device("cpu"))
+    sums = {}
+    for part in ("seg_state_dict", "flow_state_dict"):
+        sums[part] = (len(params[0][part]), float(sum(float(v.double().sum()) for v in params[0][part].values())))
+    parallel.barrier()
+    q.put((rank, len(params), sums, bool(trainer.mixed_precision)))
+    torch.distributed.destroy_process_group()
+
+
+def test_product_api_weight_broadcast_two_ranks(tmp_path):
+    """the weight broadcast sits in the product API (cineflow.predict.load_model_and_checkpoint_files), in front of the
+    patient loop of the --part_id/--num_parts path (reference contract: nnunet/inference/predict.py:743,806-821).  Rank 0 reads
+    fold_0/model_final_checkpoint.model; rank 1 has plans.json only and must end up with the same tensors."""
+    import json
+    import shutil
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "cardiac-segmentation-optical-flow_amd"))
+    from cineflow import predict
+    from cineflow.models import Generic_UNet, SegFlowGaussian
+    from cineflow.weights import seeded_state_dict
+    reduced = dict(in_dims=[6, 16, 32], out_encoder_dims=[8, 16, 32], d_model=32, bottleneck_heads=4, dim_feedforward=48)
+    plans = predict.default_plans(image_size=64, crop_size=64, flow_variant="video", seg_base=8, seg_pool=3, reduced=reduced)
+    seg = Generic_UNet(1, 8, 4, 3)
+    flow = SegFlowGaussian(image_size=64, motion_appearance=False, **reduced)
+    seg_sd = seeded_state_dict({k: v for k, v in seg.state_shapes().items()}, seed=3)
+    flow_sd = seeded_state_dict({k: v for k, v in flow.state_shapes().items() if not k.endswith("grid")}, seed=4)
+    f0, f1 = str(tmp_path / "rank0"), str(tmp_path / "rank1")
+    predict.save_model_folder(f0, seg, flow, plans, seg_sd=seg_sd, flow_sd=flow_sd)
+    os.makedirs(f1)
+    shutil.copy(os.path.join(f0, "plans.json"), f1)
+    assert sorted(os.listdir(f1)) == ["plans.json"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_api_worker, args=(r, 2, port, q, [f0, f1])) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want_seg = float(sum(float(v.double().sum()) for v in seg_sd.values()))
+    want_flow = float(sum(float(v.double().sum()) for v in flow_sd.values()))
+    for rank, nfold, sums, mp_flag in res:
+        assert nfold == 1 and mp_flag is True
+        assert sums["seg_state_dict"][0] == len(seg_sd) and abs(sums["seg_state_dict"][1] - want_seg) < 1e-6 * (1 + abs(want_seg))
+        assert sums["flow_state_dict"][0] == len(flow_sd) and abs(sums["flow_state_dict"][1] - want_flow) < 1e-6 * (1 + abs(want_flow))
+    assert json.load(open(os.path.join(f1, "plans.json")))["num_classes"] == 4

@@ -6,6 +6,7 @@ mkdir -p gpurun_out
 for step in "$@"; do
     set -- $step
     secs=$1; log=$2; shift 2
+    mkdir -p "$(dirname "gpurun_out/$log")"
     echo "=== [$(date +%H:%M:%S)] $* (limit ${secs}s) -> gpurun_out/$log"
     timeout -k 10 "$secs" "$@" > "gpurun_out/$log" 2>&1
     rc=$?

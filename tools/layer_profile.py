@@ -31,6 +31,17 @@ def shape_key(name, args, kw):
         x, slope, cout = args[0], args[2], args[6]
         B, C, H, W = x.shape
         return "conv2d_f16s_prenorm B%d C%d %dx%d -> %d k3 s1 %s gn" % (B, C, H, W, cout, "gelu" if slope < 0 else "lrelu"), 2.0 * B * H * W * cout * C * 9
+    if name == "conv2d_wino":               # (x1, wpk, wscale, bias, cout, x2=, act=, ..., stats_groups=)
+        x1, cout = args[0], args[4]
+        x2 = kw.get("x2")
+        c2 = 0 if x2 is None else x2.shape[1]
+        B, C1, H, W = x1.shape
+        return "conv2d_wino B%d C%d+%d %dx%d -> %d k3 s1%s%s" % (B, C1, c2, H, W, cout, " act=" + str(kw.get("act")) if kw.get("act") else "",
+                                                                " gn" if kw.get("stats_groups") else ""), 2.0 * B * H * W * cout * (C1 + c2) * 9
+    if name == "conv2d_wino_prenorm":       # (x, coef, slope, wpk, wscale, bias, cout, stats_groups=)
+        x, slope, cout = args[0], args[2], args[6]
+        B, C, H, W = x.shape
+        return "conv2d_wino_prenorm B%d C%d %dx%d -> %d k3 s1 %s gn" % (B, C, H, W, cout, "gelu" if slope < 0 else "lrelu"), 2.0 * B * H * W * cout * C * 9
     if name == "conv2d_small_cin":          # (x, weight, bias, stats_groups)
         x, w = args[0], args[1]
         B, C, H, W = x.shape
@@ -76,7 +87,7 @@ def main():
     lab[:, 100:156, 100:156] = 1
     bench.run_step(fnet, snet, frames, lab)
     torch.cuda.synchronize()
-    for n in ("conv2d_f16s", "conv2d_f16s_prenorm", "conv2d_small_cin", "group_norm_coef", "conv_transpose2d_k2s2_f16s", "group_norm_apply", "group_norm", "layer_norm_cf", "attention_cf", "corr_volume",
+    for n in ("conv2d_f16s", "conv2d_f16s_prenorm", "conv2d_wino", "conv2d_wino_prenorm", "conv2d_small_cin", "group_norm_coef", "conv_transpose2d_k2s2_f16s", "group_norm_apply", "group_norm", "layer_norm_cf", "attention_cf", "corr_volume",
               "warp_bilinear", "binary", "copy_channels", "gru_reset_mul", "gru_blend", "tta_accumulate", "warp_labels", "memory_input"):
         wrap(n)
     # modules bound `ops.X` at call time through the module attribute, so the wrappers are picked up

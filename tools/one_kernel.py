@@ -20,6 +20,25 @@ if kind == "conv":
     wpk, ws = ops.pack_conv_weight_f16s(w)
     for _ in range(5):
         ops.conv2d_f16s(x1, wpk, ws, None, Cout, k, k, stride, (k // 2, k // 2), x2=x2)
+elif kind == "wino":         # python tools/one_kernel.py wino C1 C2 H Cout B ntw [prenorm: gelu|lrelu]
+    from cineflow._lib import lib
+    C1, C2, H, Cout, B, ntw = (int(v) for v in sys.argv[2:8])
+    act = sys.argv[8] if len(sys.argv) > 8 else None
+    lib().cf_conv_wino_enable(ntw)
+    x1 = torch.randn(B, C1, H, H, generator=g).to(dev)
+    x2 = torch.randn(B, C2, H, H, generator=g).to(dev) if C2 else None
+    w = (torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt((C1 + C2) * 9)).to(dev)
+    wpk, wsc = ops.pack_conv_weight_wino(w)
+    groups = 8 if act != "lrelu" else Cout
+    if act:
+        wpd, wsd = ops.pack_conv_weight_f16s(w)
+        _, ws = ops.conv2d_f16s(x1, wpd, wsd, None, Cout, 3, 3, 1, (1, 1), stats_groups=groups)
+        coef = ops.group_norm_coef(ws.clone(), None, None, groups, B, C1, H * H)
+    for _ in range(5):
+        if act:
+            ops.conv2d_wino_prenorm(x1, coef, -1.0 if act == "gelu" else 0.01, wpk, wsc, None, Cout, stats_groups=groups)
+        else:
+            ops.conv2d_wino(x1, wpk, wsc, None, Cout, x2=x2, stats_groups=groups)
 elif kind == "corr":
     C, H, s, B = (int(v) for v in sys.argv[2:6])
     a, b = torch.randn(B, C, H, H, generator=g).to(dev), torch.randn(B, C, H, H, generator=g).to(dev)
