@@ -121,10 +121,32 @@ def load_nets(nets, dev, seed, world, rank):
     return nets
 
 
-def run_step(fnet, snet, frames, ed_labels):
+def run_step(fnet, snet, frames, ed_labels, seg_mixed_precision=False):
     """one step of BASELINE config 4 (tools/layer_profile.py times the same call)"""
     from cineflow.inference import predict_cine_slices
-    return predict_cine_slices(fnet, snet, frames, ed_labels)
+    return predict_cine_slices(fnet, snet, frames, ed_labels, seg_mixed_precision=seg_mixed_precision)
+
+
+def seg_precision_parity(fnet, snet, frames, ed_labels):
+    """--seg-precision f16: what the one-term segmentation path changes against the f32-class path on the SAME inputs (the first 4 slices of
+    the bench batch): per-class Dice of the label maps (the north-star bar is 1e-3), fraction of differing voxels, max |softmax difference|;
+    the flow and the propagated labels do not depend on the switch (the flow network stays f32-class)."""
+    import numpy as np
+    n = min(4, frames.shape[1])
+    fr = frames[:, :n].contiguous()
+    ed = None if ed_labels is None else ed_labels[:n].contiguous()
+    a = run_step(fnet, snet, fr, ed, False)
+    b = run_step(fnet, snet, fr, ed, True)
+    sa, sb = a["seg"].cpu().numpy(), b["seg"].cpu().numpy()
+    dice = []
+    for k in range(4):
+        ta, tb = sa == k, sb == k
+        den = ta.sum() + tb.sum()
+        dice.append(None if den == 0 else round(float(2.0 * (ta & tb).sum() / den), 6))
+    return {"dice_vs_f32_class_path": dice, "min_dice": min(d for d in dice if d is not None),
+            "voxels_differing": round(float((sa != sb).mean()), 7), "max_abs_softmax_diff": round(float((a["softmax"] - b["softmax"]).abs().max()), 5),
+            "max_abs_flow_diff_px": round(float((a["flow"] - b["flow"]).abs().max()), 7),      # run-to-run noise of the statistics atomics: the flow network is untouched
+            "dice_bar_1e-3_holds": bool(min(d for d in dice if d is not None) >= 0.999), "slices": n, "frames": int(frames.shape[0])}
 
 
 def cpu_baseline(variant, seed, T_sample):
@@ -336,7 +358,9 @@ def bench_joint(args, dev, h, world, rank):
     frames = synthetic_cine(B, T, S, 1234 + rank).to(dev)
     ed_labels = ring_labels(B, S).to(dev)
     log("joint: weights + inputs resident (rank %d/%d, B=%d, T=%d)" % (rank, world, B, T))
-    dt = timed(lambda: run_step(fnet, snet, frames, ed_labels), args.steps, args.warmup, h, dev, "joint")
+    mp = args.seg_precision == "f16"
+    parity = seg_precision_parity(fnet, snet, frames, ed_labels) if (mp and rank == 0) else None
+    dt = timed(lambda: run_step(fnet, snet, frames, ed_labels, mp), args.steps, args.warmup, h, dev, "joint")
     roofline = conv_roofline(h, dt)
     corr = [read_profile(h, k) for k in (3, 4, 5)]
     tot = tuple(sum(c[i] for c in corr) for i in range(3))
@@ -350,13 +374,17 @@ def bench_joint(args, dev, h, world, rank):
         "metric": "cine frames/sec (seg+flow) at 256x256",
         "value": round(frames_total / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 MFMA hi/lo split, f32 accumulate (f32-class)" if args.conv_mode == "f16s" else "f32", "data": "synthetic",
+        "dtype": ("f16 MFMA, f32 accumulate: flow network hi/lo split (f32-class), segmentation U-Net one-term (fp16 operands)" if mp else
+                  "f16 MFMA hi/lo split, f32 accumulate (f32-class)") if args.conv_mode == "f16s" else "f32", "data": "synthetic",
         "config": {"workload": "BASELINE config 4: joint seg+flow over 256x256x%d cine slices; Generic_UNet(32 base, 6 pools) 4-flip TTA on "
                                "every frame + %s two-chunk ED-anchored recurrence + fused label warp"
                                % (T, "ModelWrap(OpticalFlowModelSuccessive x 2, successive.yaml: d_model 512, 8 heads)" if args.variant == "successive"
                                   else "SegFlowGaussian(%s.yaml)" % args.variant),
                    "slices_per_step_per_gpu": B, "frames_per_slice": T, "image": "256x256", "sharding": "patients, rank = part_id"},
         "roofline": roofline, "roofline_corr": roofline_corr,
+        **({"seg_precision": "f16: the segmentation U-Net's convolutions in the one-term product mode (operands rounded to fp16, fp32 accumulate / norms) = "
+                             "the reference's mixed_precision=True on that path; the flow network stays f32-class.  NOT the headline configuration "
+                             "(default: --seg-precision f32)", "seg_precision_parity": parity} if mp else {}),
     }
 
 
@@ -559,6 +587,9 @@ def main():
     ap.add_argument("--no-raft", action="store_true", help="skip the nested BASELINE config 3 measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-mode", default="f16s", choices=["f16s", "f32"], help="f16s: f16-MFMA hi/lo split (default); f32: exact fp32 MFMA")
+    ap.add_argument("--seg-precision", default="f32", choices=["f32", "f16"],
+                    help="f32 (default, the headline): every network f32-class; f16: the segmentation U-Net in the one-term fp16 product mode "
+                         "(the reference's mixed_precision=True on the segmentation path), reported as a second, labelled line with its parity figures")
     ap.add_argument("--cpu-frames", type=int, default=30, help="frames of the one-slice CPU baseline sample (30 = one whole cine slice, ~15 s on 16 cores)")
     ap.add_argument("--dry-run", action="store_true", help="exercise the multi-rank path on gloo / CPU tensors without GPU work")
     args = ap.parse_args()

@@ -49,6 +49,7 @@ SIGNATURES = {
     "cf_conv2d_f16s_prenorm_ok": [I, I, I, I, I],
     "cf_conv_stream_enable": [I],
     "cf_conv2d_f16s_prenorm": [P, I, P, F, P, P, P, I, I, I, I, F, P, I, P],
+    "cf_conv_terms": [I],
     "cf_conv_wino_enable": [I],
     "cf_conv2d_wino_ok": [I, I, I, I, I, I, I],
     "cf_conv2d_wino": [P, I, P, I, P, P, P, P, I, I, I, I, I, I, I, F, P, I, P],

@@ -308,7 +308,7 @@ def _side_stream(dev):
     return _side[key]
 
 
-def predict_cine_slices(flow_net, seg_net, frames, ed_labels=None, do_mirroring=True, mirror_axes=(0, 1)):
+def predict_cine_slices(flow_net, seg_net, frames, ed_labels=None, do_mirroring=True, mirror_axes=(0, 1), seg_mixed_precision=False):
     """The joint hot path of BASELINE.json config 4 for a batch of slices that are already cropped to the network's
     patch (SegFlowGaussian._internal_maybe_mirror_and_pred_2D :3120-3230 + _internal_predict_2D_2Dconv_tiled_flow
     :3427, with the segmentation coming from the 2-D U-Net because SegFlowGaussian.forward has no 'seg' output --
@@ -316,10 +316,14 @@ def predict_cine_slices(flow_net, seg_net, frames, ed_labels=None, do_mirroring=
 
     frames [T,B,1,H,W] float32 on the GPU (B = slices x patients), z-scored;  ed_labels uint8 [B,H,W] or None
     (None -> argmax of the ED frame's segmentation is propagated).
+    seg_mixed_precision: the segmentation U-Net's convolutions run in the one-term product mode (ops.conv_terms(1): operands rounded to fp16,
+    fp32 accumulation and norms) -- the reference's `mixed_precision=True` on the segmentation path (neural_network.py:140-146); the flow
+    network always stays f32-class (SegFlowGaussian.py:2905-2909).
     Returns dict(seg uint8 [T,B,H,W], softmax [T,B,K,H,W], flow [T,B,2,H,W] (frame 0 zero), registered uint8 [T,B,H,W]).
     """
     T, B, _, H, W = frames.shape
     dev = frames.device
+    seg_terms = 1 if seg_mixed_precision else 3
     # segmentation: every frame of every slice is independent -> one batch, flip-TTA on the softmax (:3165-3226).  It does not depend on the
     # flow recurrence, so it CAN be issued on a second HIP stream: the recurrence's small launches (attention, gates, 32x32 maps) leave CUs
     # idle that the U-Net's large launches fill (opt-in, see TWO_STREAMS)
@@ -327,11 +331,12 @@ def predict_cine_slices(flow_net, seg_net, frames, ed_labels=None, do_mirroring=
     if TWO_STREAMS:
         side = _side_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), ops.conv_terms(seg_terms):
             probs = mirror_and_predict_2d(seg_net, frames.reshape(T * B, 1, H, W), mirror_axes, do_mirroring)
             seg = ops.argmax_channels(probs).view(T, B, H, W)
     else:
-        probs = mirror_and_predict_2d(seg_net, frames.reshape(T * B, 1, H, W), mirror_axes, do_mirroring)
+        with ops.conv_terms(seg_terms):
+            probs = mirror_and_predict_2d(seg_net, frames.reshape(T * B, 1, H, W), mirror_axes, do_mirroring)
         seg = ops.argmax_channels(probs).view(T, B, H, W)
     # flow: two half sequences that both start at ED, the second one backwards in time (:3120-3127); flow is not
     # TTA-averaged (:3162).  Both chunks run as one batch of 2B sequences when they have equal length.

@@ -158,6 +158,21 @@ def set_conv_mode(mode):
     CONV_MODE = mode
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def conv_terms(terms):
+    """Product mode of the f16-MFMA convolutions launched from this thread inside the block (cf_conv_terms): 3 = hi/lo split (f32-class,
+    the default), 1 = hi x hi only -- operands rounded to fp16, fp32 accumulation: the reference's fp16 autocast on the segmentation path
+    (mixed_precision=True, neural_network.py:140-146).  The flow path never runs in mode 1 (SegFlowGaussian.py:2905-2909 forces it off)."""
+    prev = lib().cf_conv_terms(int(terms))
+    try:
+        yield
+    finally:
+        lib().cf_conv_terms(prev)
+
+
 def f16s_supported(kh, kw, stride, pad):
     """kernel shapes of conv_f16s.hip: 3x3 pad 1 and 1x1 pad 0 at stride 1 / 2; the separable 1x5 pad (0,2) / 5x1 pad (2,0) of RAFT's
     SepConvGRU at stride 1.  (The 7x7 convolution of the 2-channel flow in RAFT's motion encoder stays on the exact fp32 kernel by

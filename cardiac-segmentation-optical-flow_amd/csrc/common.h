@@ -123,6 +123,23 @@ __device__ __forceinline__ float sample_taps(const float* __restrict__ plane, co
                      __fmul_rn(d, t.w11));
 }
 
+// Per-device bookkeeping for the launchers (a process may drive several GPUs): the current device's index (0 when out of the table's range)
+// and its compute-unit count rounded down to whole groups of 8 XCDs (256 on an MI355X in SPX mode; 256 when the query fails).
+static inline int current_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    return dev;
+}
+static inline int device_cu_count() {
+    static int n[64] = {};
+    const int dev = current_device_slot();
+    if (!n[dev]) {
+        hipDeviceProp_t prop;
+        n[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) ? (prop.multiProcessorCount & ~7) : 256;
+    }
+    return n[dev];
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -25,6 +25,8 @@ struct ConvParams {
     // vector staging only): per (sample, channel) {mean, scale, shift}, float [B][3][C1]; value = lrelu((x - mean) * scale + shift)
     const float* in_norm = nullptr;
     float in_slope = 1.0f;   // LeakyReLU slope; in_slope < 0 selects GELU (erf form) instead
+    int terms = 3;          // f16-split kernels: 3 = hi/lo split, three MFMAs per k-step (f32-class, the default); 1 = hi x hi only ("mixed precision":
+                            // operands rounded to fp16, fp32 accumulation -- the segmentation path under mixed_precision=True, cf_conv_terms)
     int probe = 0;          // 1: run the dispatch and its checks only, launch nothing (capability query)
     int profile_kid = -1;   // >= 0: time this launch under that profile id with `profile_work` instead of the conv's own id / flops
     double profile_work = 0.0;
@@ -34,6 +36,7 @@ struct ConvParams {
 int launch_conv(const ConvParams& p, hipStream_t s);
 
 // f16 hi/lo-split kernel (conv_f16s.hip)
+int conv_terms();           // this thread's cf_conv_terms setting (1 | 3)
 bool conv_f16s_supported(const ConvParams& p);
 int launch_conv_f16s(const ConvParams& p, const _Float16* wpk, hipStream_t s);
 

@@ -78,7 +78,10 @@ __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
 __device__ unsigned long long g_f16s_phase[9];   // [6..8]: epilogue split: scale + activation, coordinates + stores, statistics
 #define F16S_CLK() __builtin_readcyclecounter()
 #endif
-template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE, int WL>
+// TERMS = 3: the hi/lo split (al*bh + ah*bl + ah*bh); TERMS = 1: ah*bh only -- operands rounded to fp16, fp32 accumulation: what the reference's
+// fp16 autocast computes on the segmentation path (mixed_precision=True, nnunet/network_architecture/neural_network.py:140-146), selected per
+// thread by cf_conv_terms(1).  Same staging, same packed weights (the lo planes are simply not multiplied).
+template <int KH, int KW, int CK, int WM, int NTW, int MAXT, int NLW, int NW, int VEC, int PRE, int WL, int TERMS>
 __global__ void __launch_bounds__(64 * NW + 64 * NLW, NLW ? 5 : (NW == 8 ? 4 : ((NTW <= 2 && MAXT <= 3) ? 4 : 2)))
 conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restrict__ wpk) {
     constexpr int KHW = KH * KW;           // taps: 3x3, 1x1, and the separable 1x5 / 5x1 of RAFT's SepConvGRU
@@ -416,8 +419,10 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
                         const unsigned char* rp = xb + b_rec[nt] + toff + ks * 32;
                         const f16x8 bh = *reinterpret_cast<const f16x8*>(rp);
                         const f16x8 bl = *reinterpret_cast<const f16x8*>(rp + CK * 2);
-                        acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
-                        acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                        if constexpr (TERMS == 3) {
+                            acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+                            acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                        }
                         acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nt], 0, 0, 0);
                     }
                 }
@@ -499,8 +504,10 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(rp);
                 const f16x8 bl = *reinterpret_cast<const f16x8*>(rp + CK * 2);
                 // small terms first, then the main term, into one accumulator
-                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
-                acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                if constexpr (TERMS == 3) {
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc1[nt], 0, 0, 0);
+                    acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc1[nt], 0, 0, 0);
+                }
                 acc1[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc1[nt], 0, 0, 0);
             }
         }
@@ -736,6 +743,10 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// cf_conv_terms: per-thread product mode of the f16-split convolutions launched from this thread (3 = hi/lo split, 1 = hi x hi only)
+static thread_local int t_conv_terms = 3;
+int conv_terms() { return t_conv_terms; }
+
 static int f16s_deint() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("CF_F16S_DEINT"); v = e ? atoi(e) : 1; }
@@ -830,11 +841,12 @@ static int launch_f16s_v(const ConvParams& p, F16sGeom g, const _Float16* wpk, h
         return CF_ERR_ARG;
     }
     if (p.probe) return CF_OK;
-    auto kern = conv_f16s_kernel<KH, KW, CK, WM, NTW, MAXT, NLW, NW, VEC, PRE, WL>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    auto kern = p.terms == 1 ? conv_f16s_kernel<KH, KW, CK, WM, NTW, MAXT, NLW, NW, VEC, PRE, WL, 1> : conv_f16s_kernel<KH, KW, CK, WM, NTW, MAXT, NLW, NW, VEC, PRE, WL, 3>;
+    static bool attr_set[64][2] = {};       // per device and variant
+    const int dev = current_device_slot();
+    if (!attr_set[dev][p.terms == 1]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set[dev][p.terms == 1] = true;
     }
     dim3 grid((unsigned)(g.tiles_x * g.tiles_y * g.bgroups), (unsigned)((p.Cout + 32 * WM - 1) / (32 * WM)));
     dim3 block(64 * NW + 64 * NLW);
@@ -1150,6 +1162,12 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
 
 using namespace cf;
 
+extern "C" int cf_conv_terms(int terms) {
+    const int prev = t_conv_terms;
+    if (terms == 1 || terms == 3) t_conv_terms = terms;
+    return prev;
+}
+
 extern "C" int cf_conv2d_f16s(const float* x1, int C1, const float* x2, int C2, const void* wpk, const float* bias, const float* res,
                               float* out, int out_ctotal, int out_coff, int B, int H, int W, int Cout, int KH, int KW, int stride,
                               int pad_h, int pad_w, int act, float alpha, double* gn_ws, int gn_groups, void* stream) {
@@ -1165,6 +1183,7 @@ extern "C" int cf_conv2d_f16s(const float* x1, int C1, const float* x2, int C2, 
     p.pad_h = pad_h; p.pad_w = pad_w; p.Ho = (H + 2 * pad_h - KH) / stride + 1; p.Wo = (W + 2 * pad_w - KW) / stride + 1;
     p.out_ctotal = out_ctotal; p.out_coff = out_coff; p.act = act; p.alpha = alpha; p.scatter2x2 = 0;
     p.gn_ws = gn_ws; p.gn_groups = gn_groups < 0 ? -gn_groups : gn_groups; p.gn_prezeroed = gn_groups < 0;
+    p.terms = conv_terms();
     CF_REQUIRE(!gn_ws || (p.gn_groups > 0 && Cout % p.gn_groups == 0 && out_coff == 0 && out_ctotal == Cout), "bad GroupNorm statistics request");
     CF_REQUIRE(p.Ho > 0 && p.Wo > 0, "empty output");
     CF_REQUIRE(conv_f16s_supported(p), "unsupported configuration for the f16-split kernel (3x3 pad 1 or 1x1 pad 0 at stride 1/2, 1x5 pad (0,2) or 5x1 pad (2,0) at stride 1; one sample < 2 GiB)");
@@ -1183,6 +1202,7 @@ static void prenorm_params(ConvParams& p, const float* x, int C, const float* bi
     p.pad_h = 1; p.pad_w = 1; p.Ho = H; p.Wo = W; p.out_ctotal = Cout; p.out_coff = 0; p.act = CF_ACT_NONE; p.alpha = alpha; p.scatter2x2 = 0;
     p.gn_ws = gn_ws; p.gn_groups = gn_groups < 0 ? -gn_groups : gn_groups; p.gn_prezeroed = gn_groups < 0;
     p.in_norm = in_norm; p.in_slope = in_slope;
+    p.terms = conv_terms();
 }
 
 extern "C" int cf_conv2d_f16s_prenorm_ok(int B, int C, int H, int W, int Cout) {
@@ -1229,6 +1249,7 @@ extern "C" int cf_conv_transpose2d_k2s2_f16s(const float* x, const void* wpk, co
     p.C1 = Cin; p.C2 = 0; p.B = B; p.H = H; p.W = W; p.Cout = Cout * 4; p.KH = 1; p.KW = 1; p.stride = 1;
     p.pad_h = 0; p.pad_w = 0; p.Ho = H; p.Wo = W; p.out_ctotal = out_ctotal; p.out_coff = out_coff; p.act = CF_ACT_NONE;
     p.alpha = alpha; p.scatter2x2 = 1; p.gn_ws = gn_ws; p.gn_groups = gn_groups < 0 ? -gn_groups : gn_groups; p.gn_prezeroed = gn_groups < 0;
+    p.terms = conv_terms();
     CF_REQUIRE(!gn_ws || (p.gn_groups > 0 && Cout % p.gn_groups == 0 && out_coff == 0 && out_ctotal == Cout), "bad GroupNorm statistics request");
     CF_REQUIRE(conv_f16s_supported(p), "unsupported configuration for the f16-split kernel (one sample of the input must stay below 2 GiB)");
     return launch_conv_f16s(p, reinterpret_cast<const _Float16*>(wpk), as_stream(stream));

@@ -814,17 +814,7 @@ int wino_level() {
 int wino_enabled() { return wino_level() != 0; }
 int wino_force_ntw() { const int v = wino_level(); return (v == 2 || v == 4) ? v : 0; }
 
-int wino_num_cus() {
-    static int n[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (!n[dev]) {
-        hipDeviceProp_t prop;
-        n[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8) ? prop.multiProcessorCount : 256;
-    }
-    return n[dev];
-}
+int wino_num_cus() { return device_cu_count(); }
 
 bool wino_geometry(const ConvParams& p, int ntw, WinoGeom& g) {
     g.TW = p.W >= 32 ? 32 : 16;
@@ -852,9 +842,8 @@ int launch_wino(const ConvParams& p, const WinoGeom& g, const _Float16* wpk, hip
     if (lds_bytes > 160 * 1024) { set_error("conv_wino: LDS tile too large"); return CF_ERR_ARG; }
     auto kern = conv_wino_kernel<NTW, PRE>;
     static bool attr_set[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    const int dev = current_device_slot();
+    if (!attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set[dev] = true;
     }
@@ -876,14 +865,13 @@ int launch_wino_ps(const ConvParams& p, const WinoGeom& g, const _Float16* wpk, 
     const size_t lds_bytes = (size_t)2 * g.PH * g.ROWP;
     auto kern = conv_wino_ps_kernel<PRE>;
     static bool attr_set[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    const int dev = current_device_slot();
+    if (!attr_set[dev]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set[dev] = true;
     }
     const long nitems = (long)g.tiles_x * g.tiles_y * p.B * ((p.Cout + 127) / 128);
-    long nwg = wino_num_cus() & ~7;                     // one workgroup per CU, a multiple of the 8 XCDs
+    long nwg = wino_num_cus();                          // one workgroup per CU, a multiple of the 8 XCDs
     if (nwg > ((nitems + 7) & ~7L)) nwg = (nitems + 7) & ~7L;
     dim3 grid((unsigned)nwg), block(512);
     const double flops = 2.0 * (double)p.B * p.H * p.W * p.Cout * (p.C1 + p.C2) * 9.0;
@@ -923,6 +911,7 @@ int wino_pick_ntw(const ConvParams& p, WinoGeom& g) {
 // Cout: whole 128-channel blocks, or a last block at least three quarters full (the U-Net's 480), as conv_f16s' 128-channel shapes
 bool conv_wino_applicable(const ConvParams& p) {
     if (!wino_enabled()) return false;
+    if (conv_terms() != 3) return false;       // the one-term ("mixed precision") product mode is built in conv_f16s.hip only
     if (p.KH != 3 || p.KW != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1 || p.w_bstride || p.scatter2x2) return false;
     if (!(p.Cout % 128 == 0 || (p.Cout > 128 && p.Cout % 128 >= 96))) return false;
     if (p.W < 16 || (p.W & 15) != 0) return false;

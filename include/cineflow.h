@@ -132,6 +132,13 @@ int cf_conv2d(const float* x1, int C1, const float* x2, int C2, const float* wt,
 int cf_conv2d_f16s(const float* x1, int C1, const float* x2, int C2, const void* wpk, const float* bias, const float* res,
                    float* out, int out_ctotal, int out_coff, int B, int H, int W, int Cout, int KH, int KW, int stride,
                    int pad_h, int pad_w, int act, float alpha, double* gn_ws, int gn_groups, void* stream);
+/* Product mode of the f16-MFMA convolutions launched FROM THE CALLING THREAD afterwards (thread-local; returns the previous mode):
+ * 3 (default) = hi/lo operand split, three MFMAs per k-step, f32-class results; 1 = hi x hi only, i.e. operands rounded to fp16 with fp32
+ * accumulation -- what the reference's fp16 autocast gives the segmentation path under mixed_precision=True
+ * (nnunet/network_architecture/neural_network.py:140-146; the flow path forces it off, SegFlowGaussian.py:2905-2909).  In mode 1 every
+ * cf_conv2d_f16s* / cf_conv_transpose2d_k2s2_f16s call takes the one-tile kernel's hi x hi instantiation (a third of the MFMAs) and
+ * cf_conv2d_wino_ok answers 0. */
+int cf_conv_terms(int terms);
 int cf_conv_transpose2d_k2s2_f16s(const float* x, const void* wpk, const float* bias, float* out, int out_ctotal,
                                   int out_coff, int B, int Cin, int H, int W, int Cout, float alpha, double* gn_ws, int gn_groups,
                                   void* stream);

@@ -519,6 +519,62 @@ def test_long_recurrence_full_width_T16(dev):
     assert max(curve) <= 1e-4, "max per-step mean EPE %.3e" % max(curve)
 
 
+def test_config4_full_size_one_call(dev):
+    """BASELINE config 4 as ONE call at its stated size -- predict_cine_slices with the full-width video.yaml SegFlowGaussian
+    (25 M parameters) + the 32-base / 6-pool Generic_UNet on 256 x 256, T = 30, B = 2 slices: the 16 / 15-frame ED-anchored half chains share
+    launches (ragged schedule).  (i) ragged == one-after-the-other schedule to 2e-5 px; (ii) at the two chain ENDS (the frames with the longest
+    recurrence behind them: 15 and 14 steps) slice 0's flow against the fp32 CPU oracle (mean EPE <= 1e-4 px) and the propagated labels
+    (Dice within 1e-3); the oracle runs the two chains of slice 0 once (~1 min of CPU)."""
+    from cineflow.models import SegFlowGaussian, Generic_UNet
+    from cineflow import inference
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    kw = dict(image_size=256, motion_appearance=False, dim_feedforward=2048)
+    fnet = load(SegFlowGaussian(**kw), 30, dev)
+    snet = load(Generic_UNet(1, 32, 4, 6), 41, dev)
+    Tn, B = 30, 2
+    frames = smooth_cine(Tn, B, 256, 13)
+    o1, o2 = inference.chunk_orders(Tn)
+    assert len(o1) == 16 and len(o2) == 15
+    assert inference.RAGGED_CHUNKS
+    out = inference.predict_cine_slices(fnet, snet, frames.to(dev))
+    inference.RAGGED_CHUNKS = False
+    try:
+        seq = inference.predict_cine_slices(fnet, snet, frames.to(dev))
+    finally:
+        inference.RAGGED_CHUNKS = True
+    assert out["flow"].shape == (Tn, B, 2, 256, 256) and out["registered"].shape == (Tn, B, 256, 256)
+    # not bit-identical: the batch size picks the convolution shapes (fp32 summation order) and the order of the statistics atomics, and 15
+    # recurrence steps of a randomly initialised 25 M-parameter network amplify that noise where the flow field is steep: the schedules agree
+    # to ~1e-6 px in the mean; the worst single pixel of the 7.9 M is printed
+    dm = float(torch.sqrt(((out["flow"] - seq["flow"]) ** 2).sum(2)).mean())
+    d = float((out["flow"] - seq["flow"]).abs().max())
+    print("config 4 full size: ragged vs sequential schedule: mean EPE %.2e px, max |diff| %.2e px" % (dm, d))
+    assert dm <= 2e-5 and d <= 2e-3, "ragged vs sequential schedule: mean EPE %.3e px, max |flow diff| %.3e px" % (dm, d)
+    assert float((out["registered"] == seq["registered"]).float().mean()) >= 0.9999
+    assert float((out["seg"] == seq["seg"]).float().mean()) >= 0.9999
+    # ---- oracle on slice 0: both chains once, the ED segmentation, the label warp at the chain ends
+    ofnet = fill_module_(OM.SegFlowGaussian(**kw), 30)
+    osnet = fill_module_(OM.GenericUNet2D(1, 32, 4, 6), 41)
+    ends = (o1[-1], o2[-1])
+    with torch.no_grad():
+        ref = {}
+        for order in (o1, o2):
+            bf = ofnet(frames[order][:, :1])["backward_flow"]
+            ref[order[-1]] = bf[-1]                                            # [1,2,256,256]: ED -> chain end
+        ed_seg = OM.mirror_and_predict_2d(osnet, frames[0, :1]).argmax(1)       # [1,256,256]
+    for t in ends:
+        epe = OO.mean_epe(out["flow"][t, :1].cpu(), ref[t])
+        assert epe <= 1e-4, "chain end frame %d: mean EPE %.3e px (|flow| mean %.3f px)" % (t, epe, float(ref[t].abs().mean()))
+        reg = OO.warp_labels(ref[t][None], ed_seg[:, None].float())[0, :, 0]     # [1,256,256]
+        got = out["registered"][t, :1].cpu().numpy()
+        for k in range(4):
+            dk = OO.dice(got, reg.numpy(), k)
+            assert np.isnan(dk) or abs(dk - 1.0) <= 1e-3, "chain end frame %d class %d: Dice %.5f" % (t, k, dk)
+    assert torch.equal(out["seg"][0, :1].cpu().long(), ed_seg) or float((out["seg"][0, :1].cpu().long() == ed_seg).float().mean()) >= 0.9995
+
+
 def test_generic_unet_bench_width_vs_oracle(dev):
     """The network the bench runs -- Generic_UNet(1, 32, 4, 6): 32 base features, 6 pools, 480-channel 4x4 bottleneck -- on two
     256x256 frames against the oracle (which golden `generic_unet.npz` ties to the reference at reduced width)."""
@@ -538,6 +594,49 @@ def test_generic_unet_bench_width_vs_oracle(dev):
     for k in range(4):
         d = OO.dice(a, b, k)
         assert np.isnan(d) or abs(d - 1.0) <= 1e-3
+
+
+def test_generic_unet_mixed_precision_measured(dev):
+    """`mixed_precision=True` on the segmentation path = the U-Net's convolutions in the one-term product mode
+    (ops.conv_terms(1): operands rounded to fp16, fp32 accumulation and norms -- the reference's fp16 autocast, neural_network.py:140-146).
+    RESULT (stated either way, as asked): on the seeded random weights every test and the bench use, the north-star Dice bar (1e-3) does NOT
+    hold -- the softmax moves by ~2e-3 and a random network's logits are near-ties, so ~0.15 % of the voxels change class (per-class Dice
+    0.992-0.999 at the bench width on 256 x 256; measured again here).  The mode therefore stays opt-in (CF_SEG_MIXED_PRECISION=1 /
+    bench.py --seg-precision f16) and the default path ignores the flag and stays f32-class.  This test pins what the mode does: softmax
+    within 2e-2 of the fp32 oracle, per-class Dice >= 0.99, through the plain forward and through BASELINE config 1's sliding window; and that
+    leaving the block restores the three-term mode (5e-5)."""
+    from cineflow import ops
+    from cineflow.inference import mirror_and_predict_2d, predict_3D_2Dconv_tiled
+    from cineflow.models import Generic_UNet
+    from cineflow.weights import fill_module_
+    from oracle import models as OM
+    from oracle import ops as OO
+    m = load(Generic_UNet(1, 32, 4, 6), 41, dev)
+    ora = fill_module_(OM.GenericUNet2D(1, 32, 4, 6), 41)
+    x = smooth_cine(3, 1, 256, 3).reshape(3, 1, 256, 256)
+    with ops.conv_terms(1):
+        p16 = mirror_and_predict_2d(m, x.to(dev)).cpu()
+    p32 = mirror_and_predict_2d(m, x.to(dev)).cpu()
+    with torch.no_grad():
+        pref = OM.mirror_and_predict_2d(ora, x)
+    a, b = p16.argmax(1).numpy(), pref.argmax(1).numpy()
+    dice = [OO.dice(a, b, k) for k in range(4)]
+    print("one-term U-Net, 256x256: max |softmax - oracle| %.2e (three-term path: %.2e); voxels differing from the oracle's arg-max: %d of %d; Dice %s"
+          % (float((p16 - pref).abs().max()), float((p32 - pref).abs().max()), int((a != b).sum()), a.size, " ".join("%.5f" % d for d in dice)))
+    assert float((p16 - pref).abs().max()) <= 2e-2 and float((p32 - pref).abs().max()) <= 5e-5
+    assert all(np.isnan(d) or d >= 0.99 for d in dice)
+    # BASELINE config 1: sliding window + Gaussian + 4 flips with the plans' anisotropic pooling, 2 slices of the stated volume
+    pools = [[2, 2]] * 5 + [[2, 1]]
+    m1 = load(Generic_UNet(1, 32, 4, 6, pool_op_kernel_sizes=pools), 43, dev)
+    o1 = fill_module_(OM.GenericUNet2D(1, 32, 4, 6, pool_op_kernel_sizes=pools), 43)
+    vol = smooth_cine(2, 1, 256, 7)[:, 0, :, :, :216].permute(1, 0, 2, 3).contiguous().numpy()        # [1, 2, 256, 216]
+    with ops.conv_terms(1):
+        seg16, _ = predict_3D_2Dconv_tiled(m1, vol, (256, 224), step_size=0.5, do_mirroring=True, mirror_axes=(0, 1), use_gaussian=True)
+    with torch.no_grad():
+        seg_ref, _ = OM.predict_3d_2dconv_tiled(o1, vol, (256, 224), step_size=0.5, do_mirroring=True, mirror_axes=(0, 1), use_gaussian=True)
+    dice1 = [OO.dice(np.asarray(seg16), np.asarray(seg_ref), k) for k in range(4)]
+    print("one-term U-Net, config 1 sliding window: Dice %s" % " ".join("%.5f" % d for d in dice1))
+    assert all(np.isnan(d) or d >= 0.99 for d in dice1)
 
 
 # ------------------------------------------------------------------------------------------------ Processor centroid path (SURVEY 8f row 2)

@@ -933,6 +933,11 @@ STREAM_CASES = [   # B, C1, C2, H, W, Cout, groups
     (12, 81, 0, 128, 128, 64, 8),      # 81 channels: 6 chunks, zero-weight channel tail
     (10, 20, 28, 100, 132, 64, 8),     # split-aware packing (C1 = 20 padded to 2 chunks), ragged rows (100 = 12.5 tiles) and columns (132)
     (3, 64, 0, 256, 256, 64, 8),       # 768 tiles: below the threshold -> stays on conv_f16s (the knob must change nothing)
+    # the bench's map size with the kernel engaged (256 x 256: tiles_x = 8; >= 1024 tiles): the shapes that carry ~16 % of the bench step
+    (8, 32, 0, 256, 256, 32, 32),      # Generic_UNet level 0 (B960 in the bench): 1024 tiles of 16 rows
+    (8, 32, 32, 256, 256, 32, 32),     # Generic_UNet decoder level 0 on cat[skip, up]
+    (4, 64, 64, 256, 256, 64, 8),      # flow decoder conv1 on cat[skip, up] (B64 in the bench): 1024 tiles of 8 rows
+    (4, 81, 0, 256, 256, 64, 8),       # cost-volume encoder at level 0: Cin = 81
 ]
 
 
@@ -968,8 +973,36 @@ def test_conv_stream_matches_conv_f16s(dev, B, C1, C2, H, W, Cout, groups):
     check(out[-1:], ref, 1e-5, "conv_stream vs fp64")
 
 
+@pytest.mark.parametrize("C1,C2", [(81, 0), (20, 28)])
+def test_conv_stream_channel_tail_never_reads_the_next_sample(dev, C1, C2):
+    """the NaN-isolation property of conv_f16s' channel-tail parking, for the persistent kernel (route level 2): a batch whose odd
+    samples are all NaN / Inf leaves the even samples bit-identical to a clean batch (C1 = 81: 15 zero-weight tail channels in the last chunk;
+    cat[20, 28]: a tail behind each input)."""
+    from cineflow import ops
+    from cineflow._lib import lib
+    B, H, W, Cout = 16, 128, 128, 64          # 16 x 64 tiles of 8 rows = 1024: the persistent kernel engages
+    x1 = randn(B, C1, H, W, seed=70)
+    x2 = randn(B, C2, H, W, seed=71) if C2 else None
+    w = randn(Cout, C1 + C2, 3, 3, seed=72) / math.sqrt((C1 + C2) * 9)
+    wpk, ws = ops.pack_conv_weight_f16s(w.to(dev), c1=C1 if (C2 and C1 % 16) else None)
+    d = lambda t: None if t is None else t.to(dev)
+    prev = lib().cf_conv_stream_enable(2)
+    try:
+        clean = ops.conv2d_f16s(d(x1), wpk, ws, None, Cout, 3, 3, 1, (1, 1), x2=d(x2))
+        x1[1::2] = float("nan")
+        if x2 is not None:
+            x2[1::2] = float("inf")
+        both = ops.conv2d_f16s(d(x1), wpk, ws, None, Cout, 3, 3, 1, (1, 1), x2=d(x2))
+    finally:
+        lib().cf_conv_stream_enable(prev)
+    assert torch.isfinite(both[0::2]).all(), "even samples poisoned by the odd samples' values through the channel tail"
+    assert torch.equal(both[0::2], clean[0::2])
+    assert torch.isnan(both[1::2]).all()
+
+
 @pytest.mark.parametrize("B,C,H,W,Cout,act", [(20, 64, 128, 128, 64, "gelu"), (32, 32, 128, 128, 32, "lrelu"), (12, 128, 128, 128, 64, "gelu"),
-                                              (10, 96, 104, 136, 64, "lrelu")])
+                                              (10, 96, 104, 136, 64, "lrelu"),
+                                              (8, 32, 256, 256, 32, "lrelu")])     # the bench's map size (Generic_UNet level 0, second convolution)
 def test_conv_stream_prenorm_matches(dev, B, C, H, W, Cout, act):
     """deferred input normalisation (GroupNorm / InstanceNorm + GELU / LeakyReLU applied while the tile is staged) in the persistent kernel: the
     coefficient table is double buffered per tile because consecutive tiles of a workgroup belong to different samples"""
