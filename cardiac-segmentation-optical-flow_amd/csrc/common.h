@@ -140,6 +140,37 @@ static inline int device_cu_count() {
     return n[dev];
 }
 
+// Diagnostic build only (make clock -> libcineflow_hip_clock.so, never loaded by the package): every workgroup of the stamped kernels adds
+// its shader-clock and real-time-clock spans to a per-file counter, so that tools/power_probe.py can report the clock the chip HOLDS inside the
+// kernel (MI355X_MICROARCH.md, DVFS give-back item 6: delta s_memtime / delta s_memrealtime x 100 MHz).  The stamps go to a buffer no kernel reads.
+#ifdef CF_CLOCK_STAMPS
+#define CF_CLOCK_DECL(name) __device__ unsigned long long name[3];
+#define CF_CLOCK_BEGIN() const unsigned long long ck_t0_ = __builtin_amdgcn_s_memtime(), ck_r0_ = __builtin_amdgcn_s_memrealtime()
+#define CF_CLOCK_END(name)                                                                                      \
+    do {                                                                                                        \
+        if (threadIdx.x == 0) {                                                                                 \
+            atomicAdd(&name[0], (unsigned long long)(__builtin_amdgcn_s_memtime() - ck_t0_));                   \
+            atomicAdd(&name[1], (unsigned long long)(__builtin_amdgcn_s_memrealtime() - ck_r0_));               \
+            atomicAdd(&name[2], 1ULL);                                                                          \
+        }                                                                                                       \
+    } while (0)
+#define CF_CLOCK_READER(fn, name)                                                                               \
+    extern "C" int fn(double* ghz, long* workgroups) {                                                          \
+        unsigned long long v[3] = {0, 0, 0}, z[3] = {0, 0, 0};                                                  \
+        if (hipDeviceSynchronize() != hipSuccess) return CF_ERR_LAUNCH;                                         \
+        if (hipMemcpyFromSymbol(v, HIP_SYMBOL(name), sizeof(v)) != hipSuccess) return CF_ERR_LAUNCH;            \
+        if (hipMemcpyToSymbol(HIP_SYMBOL(name), z, sizeof(z)) != hipSuccess) return CF_ERR_LAUNCH;              \
+        *ghz = v[1] ? 0.1 * (double)v[0] / (double)v[1] : 0.0;                                                  \
+        *workgroups = (long)v[2];                                                                               \
+        return CF_OK;                                                                                           \
+    }
+#else
+#define CF_CLOCK_DECL(name)
+#define CF_CLOCK_BEGIN() do { } while (0)
+#define CF_CLOCK_END(name) do { } while (0)
+#define CF_CLOCK_READER(fn, name)
+#endif
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

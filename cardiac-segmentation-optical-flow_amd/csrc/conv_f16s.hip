@@ -36,6 +36,8 @@ namespace cf {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+CF_CLOCK_DECL(g_clock_f16s)
+
 struct F16sGeom {
     int TW, TH, NIMG;        // output tile of a workgroup: NIMG images x TH rows x TW cols (NIMG*TH*TW <= NT_WG*32)
     int PH, PW;              // staged patch rows / cols per image
@@ -92,6 +94,7 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     constexpr int NSTAGE = NLW ? 64 * NLW : 64 * NW;   // threads that stage
     (void)NT_WG;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    CF_CLOCK_BEGIN();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform by construction: keep it in an SGPR
@@ -726,6 +729,7 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
             }
         }
     }
+    CF_CLOCK_END(g_clock_f16s);
 #ifdef CF_F16S_ABLATION_BUILD
     if (lane == 0 && ph_t1 && (blockIdx.x & 63) == 5) {   // a sample of the workgroups: same-address atomics from every wave would dominate the run
         const unsigned long long t3 = F16S_CLK();
@@ -1161,6 +1165,8 @@ static int launch_conv_f16s_impl(const ConvParams& p, const _Float16* wpk, hipSt
 }  // namespace cf
 
 using namespace cf;
+
+CF_CLOCK_READER(cf_debug_clock_f16s, cf::g_clock_f16s)
 
 extern "C" int cf_conv_terms(int terms) {
     const int prev = t_conv_terms;

@@ -39,6 +39,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -49,8 +50,23 @@ struct WinoGeom {
     int nchunk, c1_pad;
     int ntask;                    // PH * QW * 4 staging tasks (4 channels x 4 columns) per chunk
 };
+// Timing experiments (clock build, make clock ABL=n -> -DCF_WINO_ABLATE=n; wrong results by design): 1 = staging waves skip transform + LDS
+// writes, 2 = MFMA waves skip the weight-fragment loads, 3 = MFMA waves skip the V-record reads, 4 = staging waves skip the global loads.
+// Compile-time on purpose: a run-time knob made every load conditional and the compiler's counted waits collapsed to vmcnt(0).
 
 constexpr int W_REC = 80, W_CK = 16, W_NSTEP = 12;
+CF_CLOCK_DECL(g_clock_wino)
+#ifdef CF_CLOCK_STAMPS
+// phase totals of the persistent kernel (shader clocks, lane 0 of MFMA wave 0 and of staging wave 4 of every workgroup):
+// [0] MFMA: barrier wait, [1] MFMA: chunk compute, [2] MFMA: epilogue + item setup, [3] staging: transform + LDS write, [4] staging: load issue,
+// [5] staging: barrier wait, [6] workgroups, [7] chunks
+__device__ unsigned long long g_wino_phase[8];
+#define WINO_T() __builtin_amdgcn_s_memtime()
+#define WINO_ADD(i, v) do { if (lane == 0 && (wave == 0 || wave == 4)) atomicAdd(&g_wino_phase[i], (unsigned long long)(v)); } while (0)
+#else
+#define WINO_T() 0ULL
+#define WINO_ADD(i, v) do { } while (0)
+#endif
 
 __device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
@@ -96,6 +112,7 @@ conv_wino_kernel(const ConvParams p, const WinoGeom g, const _Float16* __restric
     constexpr int VT = NTW == 4 ? 2 : 1;          // staging tasks per thread (host: ntask <= 256 * VT)
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    CF_CLOCK_BEGIN();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -434,21 +451,29 @@ conv_wino_kernel(const ConvParams p, const WinoGeom g, const _Float16* __restric
             }
         }
     }
+    CF_CLOCK_END(g_clock_wino);
 }
 
 // =====================================================================================================================================
 // Persistent, wave-specialised form (the default where a layer has enough tiles): one workgroup per CU = 4 MFMA waves (one per SIMD,
-// 128 accumulators each: m-tile w x 4 positions x 2 unit tiles) + 4 staging waves, walking a band of (128-channel block, tile) items of
-// its XCD.  Why: in the kernel above the transform / split / LDS-write stream (4.8 vector instructions per MFMA, SQ_INSTS_VALU /
-// SQ_INSTS_MFMA in profiles/r04_pmc_conv_wino.txt) sits in the SAME waves as the MFMAs and the matrix pipe is busy 53 % of the wave
-// cycles where the direct kernel reaches 84 %.  Here
+// 128 accumulators each: m-tile w x 4 positions x 2 unit tiles) + 4 staging waves (one per SIMD), walking a band of (128-channel block,
+// tile) items of its XCD.  Why: in the kernel above the transform / split / LDS-write stream (4.8 vector instructions per MFMA,
+// SQ_INSTS_VALU / SQ_INSTS_MFMA in profiles/r04_pmc_conv_wino.txt) sits in the SAME waves as the MFMAs and the matrix pipe is busy 53 %
+// of the wave cycles where the direct kernel reaches 84 %.  Here
 //   * the MFMA waves issue nothing but weight-fragment loads (three steps ahead), V-record reads (one step ahead) and MFMAs, one barrier
-//     per 16-channel chunk; their epilogue (output transform, bias, activation, 32 eight-byte stores per lane, statistics by shuffles +
-//     one fp64 atomic pair per group -- no LDS, no barrier) is the only time their pipe idles;
+//     per 16-channel chunk, and run the item's epilogue (output transform, bias, activation, 32 eight-byte stores per lane, statistics by
+//     shuffles + one fp64 atomic pair per group -- no LDS, no barrier);
 //   * the staging waves run the chunk stream ACROSS item boundaries, two chunks of loads in flight (two register sets), one LDS buffer
-//     ahead of the MFMA waves: a vector-only wave and a matrix-only wave share each SIMD, the pairing the hardware co-issues;
+//     ahead of the MFMA waves;
 //   * barrier k: "chunk k is in LDS" for the MFMA waves and "chunk k - 1 has been read" for the staging waves (which then overwrite that
-//     buffer with chunk k + 1); both roles execute exactly one barrier per chunk of the stream.
+//     buffer with chunk k + 1); both roles execute exactly one barrier per chunk of the stream (an odd stream is padded to whole pairs).
+// Where its clocks go (make clock + tools/wino_phases.py, profiles/r04_wino_phases.txt), per 16-channel chunk of 72 MFMAs = 2 304 clocks:
+// MFMA wave 3 270 in the chunk loop (2 560 without the weight-fragment loads, make clock ABL=2) + 1 110 of epilogue at 8 chunks per item
+// (the stores are issue-bound: ~8 700 clocks per item) + 300-500 at the barrier; staging wave ~2 800 for ~200 vector instructions beside
+// the MFMA wave of its SIMD (4 600-5 100 with the GELU of a deferred normalisation, which then sets the pace).  Two variants were built
+// and measured against this one and lost: the epilogue handed to the staging waves through an LDS buffer (their stores sit in the same
+// in-order vmcnt queue as the staged loads), and a 4 + 2 + 2 split with dedicated epilogue waves (two staging waves with two tasks each
+// get ~6 vector-instruction slots per MFMA of their SIMD and fall behind): -8 ... -25 %.
 // Deferred normalisation: the {mean, scale, shift} quads come straight from global memory with the chunk's loads (no LDS table: items of a
 // band cross samples).
 struct StageRegs {
@@ -464,11 +489,11 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
     constexpr int NTW = 2, REC = W_REC, CK = W_CK, NSTEP = W_NSTEP;
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    CF_CLOCK_BEGIN();
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const bool loader = wave >= 4;                        // wave-uniform
 
     // ---- this workgroup's items: band of its XCD (blocks b and b + 8 share an XCD: speed only), interleaved with the XCD's other workgroups
     const int xcd = blockIdx.x & 7, wgi = blockIdx.x >> 3, nwgx = gridDim.x >> 3;
@@ -493,60 +518,79 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
     const int buf_bytes = g.PH * g.ROWP;
     const int N = n_my * g.nchunk;                        // chunks of this workgroup's stream
 
-    if (loader) {
-        // =============================================================================================================== staging waves
-        const int task = tid - 256;
-        const bool has = task < g.ntask;
-        const int q = task % g.QW;                        // lane order (q, channel group, patch row): see conv_wino_kernel
-        const int r = task / g.QW;
-        const int cg = r & 3, py = r >> 2;
-        const bool first = q == 0, last = q == g.QW - 1;
-        const unsigned c4 = (unsigned)cg * 4u;
-        const int v_lds = py * g.ROWP + 2 * q * REC + cg * 8;
+    if (wave >= 4) {
+        // ============================================================================================================ staging waves (4 .. 7)
+        constexpr int VT = 1;                             // tasks per thread: 256 threads cover the <= 256 (row, quad, channel group) tasks of a chunk
+        bool has[VT], first[VT], last[VT];
+        unsigned c4[VT];
+        int v_lds[VT], t_py[VT], t_q[VT];
+#pragma unroll
+        for (int t = 0; t < VT; ++t) {
+            const int task = (tid - 256) + t * 256;
+            has[t] = task < g.ntask;
+            const int q = task % g.QW;                    // lane order (q, channel group, patch row): see conv_wino_kernel
+            const int r = task / g.QW;
+            const int cg = r & 3, py = r >> 2;
+            first[t] = q == 0;
+            last[t] = q == g.QW - 1;
+            c4[t] = (unsigned)cg * 4u;
+            v_lds[t] = py * g.ROWP + 2 * q * REC + cg * 8;
+            t_py[t] = py;
+            t_q[t] = q;
+        }
 
         int ld_i = 0, ld_c = 0, ld_b = 0;                 // the next chunk to load: item, chunk, its sample
-        unsigned v_off = OOB, e_off = OOB;
+        unsigned v_off[VT], e_off[VT];
         __amdgpu_buffer_rsrc_t rsrc1, rsrc2;
-        auto setup = [&](int i) {
+        auto setup = [&](int i) __attribute__((always_inline)) {
             int cb, b, y0, x0;
             decode(i, cb, b, y0, x0);
-            const int iy = y0 - 1 + py;
-            const bool row_ok = has && (unsigned)iy < (unsigned)p.H;
-            v_off = row_ok ? (unsigned)(iy * p.W + x0 + 4 * q) * 4u + c4 * HW4 : OOB;
-            const int ecol = first ? x0 - 1 : x0 + g.TW;
-            e_off = (row_ok && (first || last) && (unsigned)ecol < (unsigned)p.W) ? (unsigned)(iy * p.W + ecol) * 4u + c4 * HW4 : OOB;
+#pragma unroll
+            for (int t = 0; t < VT; ++t) {
+                const int iy = y0 - 1 + t_py[t];
+                const bool row_ok = has[t] && (unsigned)iy < (unsigned)p.H;
+                v_off[t] = row_ok ? (unsigned)(iy * p.W + x0 + 4 * t_q[t]) * 4u + c4[t] * HW4 : OOB;
+                const int ecol = first[t] ? x0 - 1 : x0 + g.TW;
+                e_off[t] = (row_ok && (first[t] || last[t]) && (unsigned)ecol < (unsigned)p.W) ? (unsigned)(iy * p.W + ecol) * 4u + c4[t] * HW4 : OOB;
+            }
             // per-sample resources: offsets at or past C * HW * 4 (the zero-weight channel tail of a chunk, parked lanes) read as 0
             rsrc1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x1 + (long)b * p.C1 * HW), 0, (int)((long)p.C1 * HW * 4), 0x00020000);
             rsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x2 ? p.x2 + (long)b * p.C2 * HW : p.x1), 0,
                                                       p.x2 ? (int)((long)p.C2 * HW * 4) : 0, 0x00020000);
             ld_b = b;
         };
-        auto issue = [&](StageRegs& R) {                  // loads chunk (ld_i, ld_c) and advances the cursor (saturating: every call loads)
+        auto issue = [&](StageRegs (&R)[VT]) __attribute__((always_inline)) {   // loads chunk (ld_i, ld_c) and advances the cursor (saturating: every call loads)
+#if defined(CF_WINO_ABLATE) && CF_WINO_ABLATE == 4
+            return;
+#endif
             const int c0 = ld_c * CK;
             const bool in1 = c0 < g.c1_pad;
             const unsigned cb = (unsigned)(in1 ? c0 : c0 - g.c1_pad);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned ch = (cb + (unsigned)j) * HW4;               // scalar
-                if (in1) {
-                    R.stg[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc1, v_off + ch, 0, 0));
-                    R.edg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc1, e_off + ch, 0, 0));
-                } else {
-                    R.stg[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc2, v_off + ch, 0, 0));
-                    R.edg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, e_off + ch, 0, 0));
+            for (int t = 0; t < VT; ++t) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned ch = (cb + (unsigned)j) * HW4;               // scalar
+                    if (in1) {
+                        R[t].stg[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc1, v_off[t] + ch, 0, 0));
+                        R[t].edg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc1, e_off[t] + ch, 0, 0));
+                    } else {
+                        R[t].stg[j] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc2, v_off[t] + ch, 0, 0));
+                        R[t].edg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, e_off[t] + ch, 0, 0));
+                    }
                 }
+                if (PRE) {
+                    const int c = c0 + (int)c4[t];                               // C1 % 4 == 0 (host): a quad is wholly inside or wholly the padded tail
+                    const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_norm + (long)ld_b * 3 * p.C1), 0,
+                                                                                        3 * p.C1 * 4, 0x00020000);
+                    const unsigned o = c < p.C1 ? (unsigned)c * 4u : OOB;
+                    R[t].cm = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rn, o, 0, 0));
+                    R[t].ca = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rn, o + (unsigned)p.C1 * 4u, 0, 0));
+                    R[t].cs = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rn, o + (unsigned)p.C1 * 8u, 0, 0));
+                }
+                R[t].valid = v_off[t] < OOB;
+                R[t].evalid = e_off[t] < OOB;
             }
-            if (PRE) {
-                const int c = c0 + (int)c4;                                  // C1 % 4 == 0 (host): a quad is wholly inside or wholly the padded tail
-                const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in_norm + (long)ld_b * 3 * p.C1), 0,
-                                                                                    3 * p.C1 * 4, 0x00020000);
-                const unsigned o = c < p.C1 ? (unsigned)c * 4u : OOB;
-                R.cm = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rn, o, 0, 0));
-                R.ca = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rn, o + (unsigned)p.C1 * 4u, 0, 0));
-                R.cs = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rn, o + (unsigned)p.C1 * 8u, 0, 0));
-            }
-            R.valid = v_off < OOB;
-            R.evalid = e_off < OOB;
             if (ld_c + 1 < g.nchunk) ++ld_c;
             else if (ld_i + 1 < n_my) { ld_c = 0; ++ld_i; setup(ld_i); }
         };
@@ -555,59 +599,81 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
             v = p.in_slope < 0.f ? gelu_as(v) : (v > 0.f ? v : v * p.in_slope);
             return valid ? v : 0.f;
         };
-        auto write = [&](const StageRegs& R, int gc) {
-            unsigned char* base = lds + (gc & 1) * buf_bytes + v_lds;
-            f16x4 hi[2][4], lo[2][4];
+        auto write = [&](const StageRegs (&RR)[VT], int gc) __attribute__((always_inline)) {
+#if defined(CF_WINO_ABLATE) && CF_WINO_ABLATE == 1
+            return;
+#endif
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float c0 = R.stg[j][0], c1 = R.stg[j][1], c2 = R.stg[j][2], c3 = R.stg[j][3], e = R.edg[j];
-                if (PRE) {
-                    c0 = pre_apply(c0, R.cm[j], R.ca[j], R.cs[j], R.valid);
-                    c1 = pre_apply(c1, R.cm[j], R.ca[j], R.cs[j], R.valid);
-                    c2 = pre_apply(c2, R.cm[j], R.ca[j], R.cs[j], R.valid);
-                    c3 = pre_apply(c3, R.cm[j], R.ca[j], R.cs[j], R.valid);
-                    e = pre_apply(e, R.cm[j], R.ca[j], R.cs[j], R.evalid);
-                }
-                float left = from_lane_below(c3), right = from_lane_above(c0);
-                left = first ? e : left;
-                right = last ? e : right;
-                const float va[4] = {left - c1, c0 + c1, c1 - c0, c0 - c2};
-                const float vb[4] = {c1 - c3, c2 + c3, c3 - c2, c2 - right};
+            for (int t = 0; t < VT; ++t) {
+                const StageRegs& R = RR[t];
+                unsigned char* base = lds + (gc & 1) * buf_bytes + v_lds[t];
+                f16x4 hi[2][4], lo[2][4];
 #pragma unroll
-                for (int pos = 0; pos < 4; ++pos) {
-                    _Float16 h, l;
-                    split_f16(va[pos], h, l);
-                    hi[0][pos][j] = h;
-                    lo[0][pos][j] = l;
-                    split_f16(vb[pos], h, l);
-                    hi[1][pos][j] = h;
-                    lo[1][pos][j] = l;
-                }
-            }
-            if (has) {
-#pragma unroll
-                for (int pos = 0; pos < 4; ++pos)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        *reinterpret_cast<f16x4*>(base + pos * g.LINE + u * REC) = hi[u][pos];
-                        *reinterpret_cast<f16x4*>(base + pos * g.LINE + u * REC + CK * 2) = lo[u][pos];
+                for (int j = 0; j < 4; ++j) {
+                    float c0 = R.stg[j][0], c1 = R.stg[j][1], c2 = R.stg[j][2], c3 = R.stg[j][3], e = R.edg[j];
+                    if (PRE) {
+                        c0 = pre_apply(c0, R.cm[j], R.ca[j], R.cs[j], R.valid);
+                        c1 = pre_apply(c1, R.cm[j], R.ca[j], R.cs[j], R.valid);
+                        c2 = pre_apply(c2, R.cm[j], R.ca[j], R.cs[j], R.valid);
+                        c3 = pre_apply(c3, R.cm[j], R.ca[j], R.cs[j], R.valid);
+                        e = pre_apply(e, R.cm[j], R.ca[j], R.cs[j], R.evalid);
                     }
+                    float left = from_lane_below(c3), right = from_lane_above(c0);
+                    left = first[t] ? e : left;
+                    right = last[t] ? e : right;
+                    const float va[4] = {left - c1, c0 + c1, c1 - c0, c0 - c2};
+                    const float vb[4] = {c1 - c3, c2 + c3, c3 - c2, c2 - right};
+#pragma unroll
+                    for (int pos = 0; pos < 4; ++pos) {
+                        _Float16 h, l;
+                        split_f16(va[pos], h, l);
+                        hi[0][pos][j] = h;
+                        lo[0][pos][j] = l;
+                        split_f16(vb[pos], h, l);
+                        hi[1][pos][j] = h;
+                        lo[1][pos][j] = l;
+                    }
+                }
+                if (has[t]) {
+#pragma unroll
+                    for (int pos = 0; pos < 4; ++pos)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            *reinterpret_cast<f16x4*>(base + pos * g.LINE + u * REC) = hi[u][pos];
+                            *reinterpret_cast<f16x4*>(base + pos * g.LINE + u * REC + CK * 2) = lo[u][pos];
+                        }
+                }
             }
         };
-        StageRegs A, B;
+        StageRegs A[VT], B[VT];
         setup(0);
         issue(A);
         issue(B);
+        unsigned long long tw = 0, ti = 0, tb = 0;
+        (void)tw; (void)ti; (void)tb;
+        // Both halves of the body are UNCONDITIONAL (an odd stream is padded by one chunk: the cursor saturates, the extra chunk lands in the
+        // buffer nobody reads any more, and the other waves execute one matching extra barrier).  With the second half under `if (gc + 1 < N)`
+        // the loop header had a predecessor on which set B had not been re-issued, and the compiler's wait for set A there came out as
+        // vmcnt(0): every other chunk waited for loads issued half an iteration earlier.
         for (int gc = 0; gc < N; gc += 2) {
+            unsigned long long t0 = WINO_T();
             write(A, gc);
+            unsigned long long t1 = WINO_T();
             issue(A);                                     // chunk gc + 2 (or the stream's last chunk again)
+            unsigned long long t2 = WINO_T();
             __syncthreads();
-            if (gc + 1 < N) {
-                write(B, gc + 1);
-                issue(B);
-                __syncthreads();
-            }
+            unsigned long long t3 = WINO_T();
+            tw += t1 - t0; ti += t2 - t1; tb += t3 - t2;
+            t0 = WINO_T();
+            write(B, gc + 1);
+            t1 = WINO_T();
+            issue(B);
+            t2 = WINO_T();
+            __syncthreads();
+            t3 = WINO_T();
+            tw += t1 - t0; ti += t2 - t1; tb += t3 - t2;
         }
+        WINO_ADD(3, tw); WINO_ADD(4, ti); WINO_ADD(5, tb);
         return;
     }
 
@@ -617,14 +683,22 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
     for (int nt = 0; nt < NTW; ++nt) b_off[nt] = (nt * g.RT + l31 / g.UW) * g.ROWP + (l31 % g.UW) * REC + half * 16;
     const long mt_stride = (long)g.nchunk * (NSTEP * 2) * 64;             // f16x8 units per m-tile
     const f16x8* const wbase = reinterpret_cast<const f16x8*>(wpk) + lane;
+    // weight-fragment ring, three steps ahead (a six-slot ring -- five steps, ~960 MFMA clocks -- took the chunk from 3 270 to 2 890 clocks
+    // in the variant whose epilogue ran in other waves, profiles/r04_wino_phases.txt, but does not fit beside this role's epilogue registers)
     constexpr int R = 4, D = R - 1;
     f16x8 aH[R] = {}, aL[R] = {};
     auto load_a = [&](const f16x8* wc, int slot) {
+#if defined(CF_WINO_ABLATE) && CF_WINO_ABLATE == 2
+        return;
+#endif
         aH[slot] = wc[0];
         aL[slot] = wc[64];
     };
-    f16x8 bH[2][NTW], bL[2][NTW];
+    f16x8 bH[2][NTW] = {}, bL[2][NTW] = {};
     auto load_b = [&](const unsigned char* xb, int step, int set) {
+#if defined(CF_WINO_ABLATE) && CF_WINO_ABLATE == 3
+        return;
+#endif
         const int toff = (step >> 2) * g.ROWP + (step & 3) * g.LINE;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
@@ -640,16 +714,15 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
 #pragma unroll
     for (int s = 0; s < D; ++s) load_a(wf + (long)s * 2 * 64, s % R);
 
+    unsigned long long tm_wait = 0, tm_comp = 0, tm_epi = 0, tm_mark = WINO_T();
+    (void)tm_wait; (void)tm_comp; (void)tm_epi; (void)tm_mark;
+    int cb_n = cb, b_n = b, y0_n = y0, x0_n = x0;          // the item after the current one (decoded once per item)
     for (int i = 0; i < n_my; ++i) {
-        decode(i, cb, b, y0, x0);
+        cb = cb_n; b = b_n; y0 = y0_n; x0 = x0_n;
         const int mt = cb * 4 + wave;
         wf = wbase + (long)mt * mt_stride;
-        const f16x8* wf_next = wf;
-        if (i + 1 < n_my) {
-            int cb2, b2, y2, x2;
-            decode(i + 1, cb2, b2, y2, x2);
-            wf_next = wbase + (long)(cb2 * 4 + wave) * mt_stride;
-        }
+        if (i + 1 < n_my) decode(i + 1, cb_n, b_n, y0_n, x0_n);
+        const f16x8* wf_next = wbase + (long)(cb_n * 4 + wave) * mt_stride;
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos)
 #pragma unroll
@@ -661,7 +734,13 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
             const int gc = i * g.nchunk + c;
             const f16x8* wc = wf + (long)c * NSTEP * 2 * 64;
             const f16x8* wn = (c + 1 < g.nchunk) ? wc + NSTEP * 2 * 64 : wf_next;      // the next chunk of the stream (the last one re-reads itself)
-            __syncthreads();                              // chunk gc is in LDS
+            {
+                const unsigned long long ta = WINO_T();
+                if (c == 0) tm_epi += ta - tm_mark; else tm_comp += ta - tm_mark;
+                __syncthreads();                          // chunk gc is in LDS
+                tm_mark = WINO_T();
+                tm_wait += tm_mark - ta;
+            }
             const unsigned char* xb = lds + (gc & 1) * buf_bytes;
             load_b(xb, 0, 0);
 #pragma unroll
@@ -682,6 +761,11 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
             }
         }
 
+        {
+            const unsigned long long ta = WINO_T();
+            tm_comp += ta - tm_mark;
+            tm_mark = ta;
+        }
         // ---- epilogue of item i (the staging waves are already one chunk into the next item)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
@@ -697,8 +781,8 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
             ssum[r] = 0.f;
             ssq[r] = 0.f;
             const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float bv = 0.f;
-            if (p.bias && co < p.Cout) bv = p.bias[co];
+            // branch-free (a clamped index and a select; sixteen `if (co < Cout)` loads were sixteen exec-mask branches per item)
+            const float bv = p.bias ? p.bias[co < p.Cout ? co : p.Cout - 1] : 0.f;
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 acc[0][nt][r] = p.alpha * acc[0][nt][r] + bv;
@@ -795,6 +879,10 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
             }
         }
     }
+    if (N & 1) __syncthreads();                           // the staging waves pad an odd chunk stream to whole pairs
+    tm_epi += WINO_T() - tm_mark;
+    WINO_ADD(0, tm_wait); WINO_ADD(1, tm_comp); WINO_ADD(2, tm_epi); WINO_ADD(6, 1); WINO_ADD(7, N);
+    CF_CLOCK_END(g_clock_wino);
 }
 
 // route level: 0 = off (every layer stays on the direct kernels), 1 = automatic (the persistent wave-specialised kernel where a layer has at
@@ -947,6 +1035,17 @@ static void wino_params(ConvParams& p, const float* x1, int C1, const float* x2,
     p.pad_h = 1; p.pad_w = 1; p.Ho = H; p.Wo = W; p.out_ctotal = out_ctotal; p.out_coff = out_coff; p.act = act; p.alpha = alpha; p.scatter2x2 = 0;
     p.gn_ws = gn_ws; p.gn_groups = gn_groups < 0 ? -gn_groups : gn_groups; p.gn_prezeroed = gn_groups < 0;
 }
+
+CF_CLOCK_READER(cf_debug_clock_wino, cf::g_clock_wino)
+#ifdef CF_CLOCK_STAMPS
+extern "C" int cf_debug_wino_phases(unsigned long long* out8) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return CF_ERR_LAUNCH;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(cf::g_wino_phase), sizeof(z)) != hipSuccess) return CF_ERR_LAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(cf::g_wino_phase), z, sizeof(z)) != hipSuccess) return CF_ERR_LAUNCH;
+    return CF_OK;
+}
+#endif
 
 extern "C" int cf_conv_wino_enable(int level) {
     const int prev = wino_level();

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Board power and shader clock (rocm-smi, polled from a thread) while one kernel runs back to back for a few seconds: is a layer's time set by the
-power limit?  python tools/power_probe.py   -> one line per workload: average / peak power, average sclk, achieved TF or TB/s."""
+power limit?  python tools/power_probe.py   -> one line per workload: average / peak power, average sclk, achieved TF or TB/s.
+With the clock build (make -C .../csrc clock; CINEFLOW_LIB=.../libcineflow_hip_clock.so python tools/power_probe.py) every convolution line also
+carries the IN-KERNEL clock: delta s_memtime / delta s_memrealtime x 100 MHz summed over the workgroups of the run (MI355X_MICROARCH.md, DVFS
+give-back item 6) -- the test the guide prescribes; rocm-smi's sclk is a coarser neighbour of it."""
 import math
 import os
 import re
@@ -14,8 +17,27 @@ sys.path.insert(0, os.path.join(ROOT, "cardiac-segmentation-optical-flow_amd"))
 import torch  # noqa: E402
 from cineflow import ops  # noqa: E402
 
+import ctypes  # noqa: E402
+from cineflow._lib import lib  # noqa: E402
+
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
+HAVE_CLOCK = hasattr(lib(), "cf_debug_clock_f16s")
+
+
+def kernel_clock():
+    """in-kernel clock of the convolutions launched since the last call (clock build only): 'x.xx GHz (n workgroups)' per kernel family"""
+    if not HAVE_CLOCK:
+        return ""
+    out = []
+    for name in ("f16s", "wino"):
+        fn = getattr(lib(), "cf_debug_clock_" + name)
+        fn.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_long)]
+        ghz, n = ctypes.c_double(), ctypes.c_long()
+        fn(ctypes.byref(ghz), ctypes.byref(n))
+        if n.value:
+            out.append("in-kernel clock %s %.3f GHz (%d workgroups)" % (name, ghz.value, n.value))
+    return " | " + ", ".join(out) if out else ""
 samples = []
 stop = False
 
@@ -35,6 +57,7 @@ def poll():
 def run(tag, fn, work, unit, secs=4.0):
     fn()
     torch.cuda.synchronize()
+    kernel_clock()           # reset the stamps: only the timed launches below count
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < secs:
@@ -46,8 +69,8 @@ def run(tag, fn, work, unit, secs=4.0):
     mine = [s for s in samples if t0 + 0.7 <= s[0] <= t1]
     pw = [s[1] for s in mine if s[1] == s[1]]
     ck = [s[2] for s in mine if s[2] == s[2]]
-    print("%-44s %7.1f %s | power avg %6.0f W peak %6.0f W (%d samples) | sclk avg %5.0f MHz" % (
-        tag, work * n / (t1 - t0), unit, sum(pw) / max(len(pw), 1), max(pw) if pw else float("nan"), len(pw), sum(ck) / max(len(ck), 1)), flush=True)
+    print("%-44s %7.1f %s | power avg %6.0f W peak %6.0f W (%d samples) | sclk avg %5.0f MHz%s" % (
+        tag, work * n / (t1 - t0), unit, sum(pw) / max(len(pw), 1), max(pw) if pw else float("nan"), len(pw), sum(ck) / max(len(ck), 1), kernel_clock()), flush=True)
 
 
 def conv_case(B, C, H, Cout, zero=False):
@@ -58,6 +81,19 @@ def conv_case(B, C, H, Cout, zero=False):
         w.zero_()
     wpk, wsc = ops.pack_conv_weight_f16s(w)
     return (lambda: ops.conv2d_f16s(x, wpk, wsc, None, Cout, 3, 3, 1, (1, 1), stats_groups=8)), 2.0 * B * H * H * Cout * C * 9 / 1e12
+
+
+def wino_case(B, C1, C2, H, Cout, zero=False):
+    x1 = torch.randn(B, C1, H, H, generator=g).to(dev)
+    x2 = torch.randn(B, C2, H, H, generator=g).to(dev) if C2 else None
+    w = (torch.randn(Cout, C1 + C2, 3, 3, generator=g) / math.sqrt((C1 + C2) * 9)).to(dev)
+    if zero:
+        x1.zero_()
+        w.zero_()
+        if x2 is not None:
+            x2.zero_()
+    wpk, wsc = ops.pack_conv_weight_wino(w)
+    return (lambda: ops.conv2d_wino(x1, wpk, wsc, None, Cout, x2=x2, stats_groups=8)), 2.0 * B * H * H * Cout * (C1 + C2) * 9 / 1e12
 
 
 th = threading.Thread(target=poll, daemon=True)
@@ -74,6 +110,14 @@ run("conv 128 -> 128, 128x128, B128 (random)", f, w_, "TF", secs=1.5 if only_cor
 if not only_corr:
     f, w_ = conv_case(128, 128, 128, 128, zero=True)
     run("conv 128 -> 128, 128x128, B128 (zeros)", f, w_, "TF")
+    f, w_ = wino_case(128, 128, 0, 128, 128)
+    run("wino 128 -> 128, 128x128, B128 (random)", f, w_, "TF")
+    f, w_ = wino_case(128, 128, 0, 128, 128, zero=True)
+    run("wino 128 -> 128, 128x128, B128 (zeros)", f, w_, "TF")
+    f, w_ = wino_case(64, 256, 256, 64, 256)
+    run("wino 256+256 -> 256, 64x64, B64 (random)", f, w_, "TF")
+    f, w_ = wino_case(64, 256, 256, 64, 256, zero=True)
+    run("wino 256+256 -> 256, 64x64, B64 (zeros)", f, w_, "TF")
     f, w_ = conv_case(128, 64, 256, 64)
     run("conv 64 -> 64, 256x256, B128 (random)", f, w_, "TF")
     f, w_ = conv_case(128, 64, 256, 64, zero=True)
