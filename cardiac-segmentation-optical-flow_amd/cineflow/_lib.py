@@ -36,6 +36,7 @@ SIGNATURES = {
     "cf_warp_trilinear_3d": [P, P, P, I, I, I, I, I, P],
     "cf_jacobian_det_3d": [P, P, I, I, I, I, P],
     "cf_corr_volume": [P, P, P, I, I, I, I, I, I, P],
+    "cf_corr_mfma_enable": [I],
     "cf_corr_pyramid": [P, P, P, I, I, I, I, I, P],
     "cf_corr_lookup": [P, P, P, I, I, I, I, I, P],
     "cf_convex_upsample": [P, P, P, I, I, I, I, P],

@@ -49,6 +49,10 @@ int launch_conv_stream(const ConvParams& p, const _Float16* wpk, hipStream_t s);
 bool conv_wino_applicable(const ConvParams& p);
 int launch_conv_wino(const ConvParams& p, const _Float16* wpk, hipStream_t s);
 
+// CorrVolume (radius 4, dilation 1 / 2 / 4) on the f16 MFMA in 2-D banded form (corr_mfma.hip); corr.hip keeps every other shape
+bool corr_mfma_applicable(int C, int H, int W, int stride, const float* cur, const float* prev);
+int launch_corr_volume_mfma(const float* cur, const float* prev, float* out, int B, int C, int H, int W, int stride, hipStream_t s);
+
 // RAFT all-pairs volume + pyramid in one kernel (allpairs.hip); returns 1 when the shape is not one it is built for
 int allpairs_pyramid_fused(const float* f1, const float* f2, float* pyr, int B, int C, int H, int W, int levels, hipStream_t stream);
 

@@ -504,6 +504,7 @@ extern "C" int cf_corr_volume(const float* cur, const float* prev, float* out, i
     CF_REQUIRE(cur && prev && out, "null pointer");
     CF_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0 && radius >= 0 && radius <= 8 && stride >= 1, "bad shape");
     hipStream_t s = as_stream(stream);
+    if (radius == 4 && corr_mfma_applicable(C, H, W, stride, cur, prev)) return launch_corr_volume_mfma(cur, prev, out, B, C, H, W, stride, s);
     if (radius == 4 && (stride == 1 || stride == 2 || stride == 4) && (W & 3) == 0 && (long)(C + P7_CC) * H * W * 4 < (1L << 31) &&
         ((reinterpret_cast<uintptr_t>(cur) | reinterpret_cast<uintptr_t>(prev)) & 15) == 0) {
         // algorithmic bytes: read cur + prev once, write the 81-channel volume once

@@ -81,6 +81,10 @@ int cf_jacobian_det_3d(const float* disp, double* det, int B, int D, int H, int 
  * out[b,(dy+r)(2r+1)+(dx+r),y,x] = mean_c cur[b,c,y,x] * prev[b,c,y+dy*stride,x+dx*stride], zero outside. */
 int cf_corr_volume(const float* cur, const float* prev, float* out, int B, int C, int H, int W, int radius, int stride,
                    void* stream);
+/* A/B knob without a reference counterpart: CorrVolume calls with radius 4, dilation 1 / 2 / 4, C % 16 == 0, W % 64 == 0 and H % (8 x dilation) == 0
+ * run on the f16-MFMA kernel (csrc/corr_mfma.hip: 2-D banded products of hi/lo-split operands, fp32 accumulation, within 1e-5 of the fp32 kernel);
+ * 0 keeps them on the fp32 vector kernel (also CF_CORR_MFMA=0).  Returns the previous setting. */
+int cf_corr_mfma_enable(int on);
 
 /* CorrBlock (published RAFT; call site SegFlowGaussian.py:929): all-pairs volume
  * corr[b, n1, n2] = sum_c f1[b,c,n1] f2[b,c,n2] / sqrt(C) into pyr level 0, then `levels`-1 2x2 average pools.

@@ -190,6 +190,29 @@ def test_corr_volume_radius4(dev, C, H, W, stride):
     check(ops.corr_volume(cur.to(dev), prev.to(dev), 4, stride), OO.corr_volume(cur, prev, 4, stride), 1e-5, "corr_volume")
 
 
+@pytest.mark.parametrize("B,C,H,W,stride", [(2, 64, 256, 256, 4), (3, 128, 128, 128, 2), (2, 256, 64, 64, 1),      # the three levels of the flow network
+                                            (5, 16, 64, 128, 4), (3, 32, 48, 192, 2), (9, 16, 24, 64, 1)])            # ragged tile counts, bands with < 1 tile
+def test_corr_volume_mfma_vs_oracle_and_vector_kernel(dev, B, C, H, W, stride):
+    """the f16-MFMA CorrVolume kernel (csrc/corr_mfma.hip: 2-D banded products of hi/lo-split operands, four split terms inside
+    one K = 32 instruction, fp32 accumulation) at the network's three levels with B >= 2, against the oracle at 1e-5 and against the fp32
+    vector kernel (cf_corr_mfma_enable(0)) on the same inputs; zero padding at every border (dilation 4: +-16 px)."""
+    from cineflow import ops
+    from cineflow._lib import lib
+    from oracle import ops as OO
+    cur, prev = randn(B, C, H, W, seed=21), randn(B, C, H, W, seed=22)
+    prev_mode = lib().cf_corr_mfma_enable(1)
+    try:
+        got = ops.corr_volume(cur.to(dev), prev.to(dev), 4, stride)
+        lib().cf_corr_mfma_enable(0)
+        vec = ops.corr_volume(cur.to(dev), prev.to(dev), 4, stride)
+    finally:
+        lib().cf_corr_mfma_enable(prev_mode)
+    want = OO.corr_volume(cur[:2], prev[:2], 4, stride)
+    check(got[:2], want, 1e-5, "corr_volume (MFMA) vs oracle")
+    check(got, vec.cpu(), 1e-5, "corr_volume (MFMA) vs the fp32 vector kernel")
+    assert got.shape == (B, 81, H, W) and bool(torch.isfinite(got).all())
+
+
 def test_corr_volume_generic_and_symmetry(dev):
     from cineflow import ops
     from oracle import ops as OO

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
     out=$GRAFT_REPO_ROOT/gpurun_out/pmc_${tag}_$c
     rm -rf "$out"
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out" -o pmc -- python3 "$GRAFT_REPO_ROOT/tools/one_kernel.py" "$@" > "$out.log" 2>&1 || { tail -5 "$out.log"; exit 1; }
+    timeout -k 10 "${PMC_TIMEOUT:-180}" rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$out" -o pmc -- python3 "$GRAFT_REPO_ROOT/tools/one_kernel.py" "$@" > "$out.log" 2>&1 || { tail -5 "$out.log"; exit 1; }
     f=$(find "$out" -name "*counter_collection.csv" | head -1)
     python3 - "$f" "$c" <<'PY'
 import csv, sys, collections
