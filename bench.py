@@ -52,7 +52,7 @@ MFMA_F16_SUSTAINED_TFLOPS = 1720.0
 # the live line carries `traffic` = algorithmic x this ratio with its source, it cannot collect counters itself (gpurun refuses --pmc next to
 # tracing, and a PMC pass serialises kernels).
 PMC_TRAFFIC_RATIO = {"conv_f16s": (1.00, "profiles/r02_pmc_hbm_traffic.md, r03_pmc_hbm_traffic.md (reads 1.00-1.03x, writes 1.00x algorithmic)"),
-                     "corr": (1.18, "profiles/r01_pmc_hbm_traffic.md, re-measured in profiles/r03_pmc_hbm_traffic.md (reads 1.28-1.33x at dilation 4, 1.02x at dilation 1, writes exact; byte-weighted 1.18x)")}
+                     "corr": (1.13, "profiles/r04_pmc_hbm_traffic.md (corr_volume_mfma_kernel: reads 1.29x at dilation 4, 1.08x at 2, 1.00x at 1, writes exact; byte-weighted 1.13x)")}
 
 
 def synthetic_cine(B, T, S, seed):
@@ -364,7 +364,7 @@ def bench_joint(args, dev, h, world, rank):
     roofline = conv_roofline(h, dt)
     corr = [read_profile(h, k) for k in (3, 4, 5)]
     tot = tuple(sum(c[i] for c in corr) for i in range(3))
-    roofline_corr = hbm_roofline("corr_volume_p7_kernel<1|2|4> (persistent)", tot, pmc="corr")
+    roofline_corr = hbm_roofline("corr_volume_mfma_kernel<1|2|4> (persistent; 2-D banded f16-MFMA products of hi/lo-split operands, fp32 accumulate)", tot, pmc="corr")
     if roofline_corr:
         roofline_corr["per_level"] = {"s%d" % s: {"GB/s": round(c[1] / (c[0] * 1e-3) / 1e9, 1), "avg_launch_us": round(c[0] * 1e3 / c[2], 2)}
                                       for s, c in zip((1, 2, 4), corr) if c[2]}
