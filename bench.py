@@ -51,6 +51,20 @@ MFMA_F16_SUSTAINED_TFLOPS = 1720.0
 # HBM bytes per launch over algorithmic bytes, from the separate PMC passes (FETCH_SIZE / WRITE_SIZE with the guide's wide-load correction):
 # the live line carries `traffic` = algorithmic x this ratio with its source, it cannot collect counters itself (gpurun refuses --pmc next to
 # tracing, and a PMC pass serialises kernels).
+# Matrix-pipe busy fraction of KERNEL WALL TIME per dominant convolution shape, from one GRBM_GUI_ACTIVE + SQ_VALU_MFMA_BUSY_CYCLES pass each
+# (tools/pmc_busy.sh; busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8); effective clock of the profiled pass = GRBM_GUI_ACTIVE / 8 /
+# wall time) and the in-kernel clock of a plain run (delta s_memtime / delta s_memrealtime, tools/power_probe.py on the clock build).  Constants
+# with their source, like PMC_TRAFFIC_RATIO: a counter pass cannot run inside the timed region.
+MFMA_BUSY = {"source": "profiles/r04_power_probe.txt (tools/pmc_busy.sh passes + tools/power_probe.py on the clock build)",
+             "conv_wino_ps_kernel 128 -> 128 @128x128 B128": {"mfma_busy_of_wall": 0.46, "clock_GHz_profiled_pass": 1.51, "in_kernel_clock_GHz_plain_run": 1.84,
+                                                             "in_kernel_clock_GHz_zero_operands": 2.39},
+             "conv_wino_ps_kernel 256+256 -> 256 @64x64 B64": {"mfma_busy_of_wall": 0.59, "clock_GHz_profiled_pass": 1.39, "in_kernel_clock_GHz_plain_run": 1.70,
+                                                              "in_kernel_clock_GHz_zero_operands": 2.39},
+             "conv_stream_kernel 64 -> 64 @256x256 B128": {"mfma_busy_of_wall": 0.54, "clock_GHz_profiled_pass": 1.48},
+             "conv_f16s_kernel 128 -> 128 @128x128 B128 (direct form, for comparison)": {"mfma_busy_of_wall": 0.76, "clock_GHz_profiled_pass": 1.29,
+                                                                                         "in_kernel_clock_GHz_plain_run": 1.53,
+                                                                                         "in_kernel_clock_GHz_zero_operands": 2.38}}
+
 PMC_TRAFFIC_RATIO = {"conv_f16s": (1.00, "profiles/r02_pmc_hbm_traffic.md, r03_pmc_hbm_traffic.md (reads 1.00-1.03x, writes 1.00x algorithmic)"),
                      "corr": (1.13, "profiles/r04_pmc_hbm_traffic.md (corr_volume_mfma_kernel: reads 1.29x at dilation 4, 1.08x at 2, 1.00x at 1, writes exact; byte-weighted 1.13x)")}
 
@@ -316,6 +330,7 @@ def conv_roofline(h, dt):
                 "flops_counted": "algorithmic (direct-form) flops of every layer, also for the Winograd kernel",
                 "mfma_issue_frac": round(issued / MFMA_F16_PEAK_TFLOPS, 4), "vs_fp32_mfma_peak": round(ach / MFMA_F32_PEAK_TFLOPS, 3),
                 "sustained_mfma_peak_measured": MFMA_F16_SUSTAINED_TFLOPS, "mfma_issue_frac_of_sustained": round(issued / MFMA_F16_SUSTAINED_TFLOPS, 4),
+                "mfma_busy": MFMA_BUSY,
                 "traffic": None, "traffic_over_algorithmic": PMC_TRAFFIC_RATIO["conv_f16s"][0], "traffic_source": PMC_TRAFFIC_RATIO["conv_f16s"][1],
                 "traffic_note": "HBM bytes per launch = algorithmic bytes (inputs read once + outputs written once, per layer shape) x traffic_over_algorithmic; "
                                 "the kernel is MFMA-bound, so the live line prices flops and carries the PMC byte ratio as a constant",

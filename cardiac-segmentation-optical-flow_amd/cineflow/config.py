@@ -124,6 +124,15 @@ def build_seg_flow_gaussian_model(config, image_size, log_function=None):
     _need(config, "legacy", (True,), what)
     _need(config, "deep_supervision", (False,), what)          # extra decoder heads (decoder_alt.py:860-889)
     _need(config, "nb_conv", (1, 2), what)
+    # keys the reference's constructor / forward also branch on and that this build does not parametrise: pinned to the value BOTH shipped
+    # configurations (video.yaml, raft_config.yaml) carry, so that a file differing in one of them fails loudly instead of silently building
+    # the default network.  memory_read = False, e.g., adds a skip reduction block at the bottleneck level
+    # (SegFlowGaussian.py skip_co_reduction loop); no_skip_co / conv_bottleneck / final_stride / cost_volume / small_memory / P change
+    # the layer lists; backward_flow / gaussian / timesformer / shrink_select / topk / marginal / pos_1d select other forward branches.
+    for key, value in (("memory_read", True), ("no_skip_co", False), ("conv_bottleneck", False), ("final_stride", 1), ("cost_volume", True),
+                       ("small_memory", False), ("P", 0), ("backward_flow", True), ("gaussian", False), ("timesformer", False),
+                       ("shrink_select", False), ("topk", False), ("marginal", True), ("pos_1d", "sin")):
+        _need(config, key, (value,), what)
     return SegFlowGaussian(image_size=image_size, in_dims=kw["in_dims"], out_encoder_dims=kw["out_encoder_dims"], d_model=kw["d_model"],
                            conv_depth=kw["conv_depth"], skip_co_depth=kw["skip_co_depth"], bottleneck_heads=kw["bottleneck_heads"],
                            nb_layers=kw["nb_layers"], dim_feedforward=kw["dim_feedforward"], motion_appearance=bool(kw["motion_appearance"]),

@@ -103,7 +103,10 @@ def test_readers_keep_the_reference_assertions_and_key_errors(fixtures, tmp_path
 
 def test_values_outside_the_hot_path_are_refused_by_name(fixtures):
     from cineflow import config as C
-    for key, val in (("label_input", True), ("skip_co_type", "past"), ("norm", "batch"), ("prediction", True), ("remove_GRU", True)):
+    for key, val in (("label_input", True), ("skip_co_type", "past"), ("norm", "batch"), ("prediction", True), ("remove_GRU", True),
+                     # keys the reference's constructor / forward branch on and the build does not parametrise (pinned to the shipped value)
+                     ("memory_read", False), ("no_skip_co", True), ("conv_bottleneck", True), ("final_stride", 2), ("cost_volume", False),
+                     ("backward_flow", False), ("gaussian", True), ("timesformer", True), ("small_memory", True), ("P", 1), ("pos_1d", "learned")):
         cfg = dict(fixtures["video"]["values"], **{key: val})
         with pytest.raises(NotImplementedError, match=key):
             C.build_seg_flow_gaussian_model(cfg, 256)
