@@ -18,9 +18,12 @@
 //     beside them every B read was waited for on the spot -- 24 exposed LDS latencies per chunk -- and the kernel ran at 2.9 TB/s.)
 //   * LDS records [x-class][row][position] of 32 bytes {hi c0..7 | lo c0..7}, the two halves SWAPPED on odd rows and row pitches = 64 (mod 256):
 //     the sixteen 16-byte reads of a 4 x 4 patch fragment (hi parts of two k-groups, or lo parts) then land on sixteen distinct slots.
-//   * persistent workgroups (one per CU) walk a band of tiles of their XCD; the chunk stream runs across tile boundaries, two chunks of loads in
-//     flight, two LDS stages, one barrier per chunk; the 81 planes of a tile leave through LDS (the stage that is free at that moment) in two
-//     halves of four rows as whole 256-byte row segments.
+//   * persistent workgroups (one per CU) walk a band of tiles of their XCD; the chunk stream runs across tile boundaries, ONE chunk of loads in
+//     flight (a single staging register set: 64 KB per CU), two LDS stages, one barrier per chunk; the 81 planes of a tile leave through LDS (the
+//     stage that is free at that moment) in two halves of four rows as whole 256-byte row segments.
+//     What bounds it (profiles/r04_corr_mfma.txt): the bytes in flight.  A second staging set (two chunks in flight) needs 16 more registers than
+//     the 128 a 1024-thread workgroup has per lane; tried twice (with every fragment register given up: one A and one B fragment live) it still
+//     spills 40-60 B per lane INSIDE the chunk loop, the reloads collapse the counted waits to vmcnt(0), and the loop gets slower, not faster.
 // Shapes: C % 8 == 0, W % 64 == 0, H % (8 S) == 0 (the three levels of the flow network: (64, 256, 4), (128, 128, 2), (256, 64, 1)); anything else
 // stays on corr.hip.  Numerics: exact products of the split operands, fp32 accumulation: within 1e-5 of the fp32 / fp64 oracle on O(1) features.
 #include <hip/hip_fp16.h>
