@@ -171,6 +171,67 @@ static inline int device_cu_count() {
 #define CF_CLOCK_READER(fn, name)
 #endif
 
+// ---- cross-lane sums without LDS traffic (gfx950).  __shfl_xor is a ds_bpermute: an LDS-queue instruction with ~100 clocks of latency per level;
+// partners inside a row of 16 lanes are reachable by DPP modifiers instead, and rows / wave halves are exchanged by v_permlane16_swap /
+// v_permlane32_swap (new on gfx950): a' = [a.row0, b.row0, a.row2, b.row2], b' = [a.row1, b.row1, a.row3, b.row3].
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;       // quad_perm [1,0,3,2] / [2,3,0,1]
+constexpr int DPP_ROR8 = 0x128;                       // row_ror:8 = lane ^ 8 inside the row
+constexpr int DPP_HALF_MIRROR = 0x141;                // lane ^ 7 inside each 8 lanes
+// Inline assembly: this hipcc's __builtin_amdgcn_permlane16_swap / 32_swap lose their second result (both members of the returned pair are the
+// new vdst: tools/ubench/xreduce_check.hip).  The s_nop pairs stand in for the hazard recogniser, which does not see inside an asm statement
+// (a VALU write of an operand needs two wait states before the swap reads it, and so does a VALU read after it).
+__device__ __forceinline__ void swap_rows16(float& a, float& b) {
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap_halves32(float& a, float& b) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+// Transpose-reduce of sixteen per-lane partial sums over the 32 lanes of a wave half: afterwards v[0] of the lane with bits (b4 b3 b2 b1 x)
+// holds register 8 b4 + 4 b3 + 2 b2 + b1 summed over those 32 lanes (both lanes of a pair hold the same).  The level that pairs on lane bit 2
+// uses the half mirror (partner lane ^ 7): the partner differs in bits 0 and 1 as well, which the two remaining levels sum over anyway.
+__device__ __forceinline__ void xreduce16(float (&v)[16], int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float a = v[i], b = v[i + 8];
+        swap_rows16(a, b);                                    // rows with bit 4 clear: own v[i] + the partner row's; set: own v[i + 8] + the partner row's
+        v[i] = a + b;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool up = (lane & 8) != 0;
+        const float keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
+        v[i] = keep + dpp_f32<DPP_ROR8>(send);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bool up = (lane & 4) != 0;
+        const float keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
+        v[i] = keep + dpp_f32<DPP_HALF_MIRROR>(send);
+    }
+    {
+        const bool up = (lane & 2) != 0;
+        const float keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+        v[0] = keep + dpp_f32<DPP_XOR2>(send);
+    }
+    v[0] += dpp_f32<DPP_XOR1>(v[0]);
+}
+// s + s of lane ^ MASK for MASK in {2, 4, 8, 16, 32}.  MASK = 4 goes through the half mirror (lane ^ 7) and is only right when s is already the
+// same on the four lanes of a quad (i.e. after the MASK = 2 level, as after xreduce16's pair sum).
+template <int MASK>
+__device__ __forceinline__ float xor_sum(float s) {
+    static_assert(MASK == 2 || MASK == 4 || MASK == 8 || MASK == 16 || MASK == 32, "lane mask");
+    if constexpr (MASK == 2) return s + dpp_f32<DPP_XOR2>(s);
+    else if constexpr (MASK == 4) return s + dpp_f32<DPP_HALF_MIRROR>(s);
+    else if constexpr (MASK == 8) return s + dpp_f32<DPP_ROR8>(s);
+    else if constexpr (MASK == 16) { float a = s, b = s; swap_rows16(a, b); return a + b; }
+    else { float a = s, b = s; swap_halves32(a, b); return a + b; }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -671,35 +671,8 @@ conv_f16s_kernel(const ConvParams p, const F16sGeom g, const _Float16* __restric
     const unsigned long long ph_e2 = F16S_CLK();
 #endif
     if (do_stats) {
-        auto xreduce = [&](float (&v)[16]) {
-            // after this, lane bits (b4 b3 b2 b1) select register 8*b4 + 4*b3 + 2*b2 + b1, summed over the 32 lanes of the half
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool up = (lane & 16) != 0;
-                const float keep = up ? v[i + 8] : v[i], send = up ? v[i] : v[i + 8];
-                v[i] = keep + __shfl_xor(send, 16, 64);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool up = (lane & 8) != 0;
-                const float keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
-                v[i] = keep + __shfl_xor(send, 8, 64);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const bool up = (lane & 4) != 0;
-                const float keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
-                v[i] = keep + __shfl_xor(send, 4, 64);
-            }
-            {
-                const bool up = (lane & 2) != 0;
-                const float keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
-                v[0] = keep + __shfl_xor(send, 2, 64);
-            }
-            v[0] += __shfl_xor(v[0], 1, 64);
-        };
-        xreduce(ssum);
-        xreduce(ssq);
+        xreduce16(ssum, lane);      // common.h: DPP + v_permlane16_swap, no LDS traffic
+        xreduce16(ssq, lane);
         // workgroup-level combine in LDS (the staging buffers are free now), then ONE fp64 atomic pair per (group, workgroup):
         // thousands of workgroups adding to the same 8 groups of a sample would otherwise serialise at the memory side.
         float* red = reinterpret_cast<float*>(lds);  // [WM*32 channels][2]

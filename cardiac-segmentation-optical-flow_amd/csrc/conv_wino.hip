@@ -59,8 +59,8 @@ CF_CLOCK_DECL(g_clock_wino)
 #ifdef CF_CLOCK_STAMPS
 // phase totals of the persistent kernel (shader clocks, lane 0 of MFMA wave 0 and of staging wave 4 of every workgroup):
 // [0] MFMA: barrier wait, [1] MFMA: chunk compute, [2] MFMA: epilogue + item setup, [3] staging: transform + LDS write, [4] staging: load issue,
-// [5] staging: barrier wait, [6] workgroups, [7] chunks
-__device__ unsigned long long g_wino_phase[8];
+// [5] staging: barrier wait, [6] workgroups, [7] chunks; inside [2]: [8] output transform + bias + activation, [9] stores + sums, [10] statistics
+__device__ unsigned long long g_wino_phase[12];
 #define WINO_T() __builtin_amdgcn_s_memtime()
 #define WINO_ADD(i, v) do { if (lane == 0 && (wave == 0 || wave == 4)) atomicAdd(&g_wino_phase[i], (unsigned long long)(v)); } while (0)
 #else
@@ -395,35 +395,8 @@ conv_wino_kernel(const ConvParams p, const WinoGeom g, const _Float16* __restric
         }
     }
     if (do_stats) {
-        auto xreduce = [&](float (&v)[16]) {
-            // after this, lane bits (b4 b3 b2 b1) select register 8*b4 + 4*b3 + 2*b2 + b1, summed over the 32 lanes of the half
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool up = (lane & 16) != 0;
-                const float keep = up ? v[i + 8] : v[i], send = up ? v[i] : v[i + 8];
-                v[i] = keep + __shfl_xor(send, 16, 64);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool up = (lane & 8) != 0;
-                const float keep = up ? v[i + 4] : v[i], send = up ? v[i] : v[i + 4];
-                v[i] = keep + __shfl_xor(send, 8, 64);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const bool up = (lane & 4) != 0;
-                const float keep = up ? v[i + 2] : v[i], send = up ? v[i] : v[i + 2];
-                v[i] = keep + __shfl_xor(send, 4, 64);
-            }
-            {
-                const bool up = (lane & 2) != 0;
-                const float keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
-                v[0] = keep + __shfl_xor(send, 2, 64);
-            }
-            v[0] += __shfl_xor(v[0], 1, 64);
-        };
-        xreduce(ssum);
-        xreduce(ssq);
+        xreduce16(ssum, lane);      // common.h: DPP + v_permlane16_swap, no LDS traffic
+        xreduce16(ssq, lane);
         // workgroup-level combine in LDS (the V buffers are free now), then ONE fp64 atomic pair per (group, workgroup)
         float* red = reinterpret_cast<float*>(lds);  // [128 channels][2]
         __syncthreads();
@@ -714,7 +687,7 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
 #pragma unroll
     for (int s = 0; s < D; ++s) load_a(wf + (long)s * 2 * 64, s % R);
 
-    unsigned long long tm_wait = 0, tm_comp = 0, tm_epi = 0, tm_mark = WINO_T();
+    unsigned long long tm_wait = 0, tm_comp = 0, tm_epi = 0, tm_e1 = 0, tm_e2 = 0, tm_e3 = 0, tm_mark = WINO_T();
     (void)tm_wait; (void)tm_comp; (void)tm_epi; (void)tm_mark;
     int cb_n = cb, b_n = b, y0_n = y0, x0_n = x0;          // the item after the current one (decoded once per item)
     for (int i = 0; i < n_my; ++i) {
@@ -790,6 +763,7 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
             }
         }
         wino_activate<NTW>(acc, p.act);
+        const unsigned long long te1 = WINO_T();
         constexpr unsigned OOB_CH = 0x40000000u;
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
             p.out + ((long)b * p.out_ctotal + p.out_coff) * (long)HW, 0, (int)((long)(p.out_ctotal - p.out_coff) * HW * 4), 0x00020000);
@@ -799,11 +773,18 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
             const int oy = y0 + nt * g.RT + l31 / g.UW, ox = x0 + 2 * (l31 % g.UW);
             o_off[nt] = (unsigned)(oy * p.W + ox) * 4u;
         }
+        // Stores: a lane holds two adjacent columns of unit u for both unit tiles (nt = 0, 1).  Adjacent lanes (units u, u + 1 of one row: UW is
+        // even) swap one pair through a DPP quad permute, after which the even lane owns four adjacent columns of tile 0 and the odd lane four of
+        // tile 1: 16 sixteen-byte stores per lane instead of 32 eight-byte ones (the store path moves ~14 B per clock and CU with dwordx4, half
+        // that with dwordx2, and the item's stores were its epilogue: profiles/r04_wino_phases.txt).
+        const bool odd = (lane & 1) != 0;
+        const unsigned st_off = odd ? o_off[1] - 8u : o_off[0];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const bool co_ok = co < p.Cout;
             const unsigned ochan = co_ok ? (unsigned)co * HW4 : OOB_CH;
+            float v[NTW][2];
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 float v0 = acc[0][nt][r], v1 = acc[1][nt][r];
@@ -814,62 +795,43 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
                         v1 += rp[1];
                     }
                 }
-                u32x2 pk;
-                pk[0] = __builtin_bit_cast(unsigned, v0);
-                pk[1] = __builtin_bit_cast(unsigned, v1);
-                __builtin_amdgcn_raw_buffer_store_b64(pk, rs_out, o_off[nt] + ochan, 0, 0);
+                v[nt][0] = v0;
+                v[nt][1] = v1;
                 const float m0 = co_ok ? v0 : 0.f, m1 = co_ok ? v1 : 0.f;
                 ssum[r] += m0 + m1;
                 ssq[r] += m0 * m0 + m1 * m1;
             }
+            const float k0 = odd ? v[1][0] : v[0][0], k1 = odd ? v[1][1] : v[0][1];      // kept: the own tile's pair
+            const int s0 = __builtin_bit_cast(int, odd ? v[0][0] : v[1][0]), s1 = __builtin_bit_cast(int, odd ? v[0][1] : v[1][1]);
+            const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(s0, s0, 0xB1, 0xf, 0xf, false));   // quad_perm [1, 0, 3, 2]
+            const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(s1, s1, 0xB1, 0xf, 0xf, false));
+            u32x4 pk;
+            pk[0] = __builtin_bit_cast(unsigned, odd ? r0 : k0);
+            pk[1] = __builtin_bit_cast(unsigned, odd ? r1 : k1);
+            pk[2] = __builtin_bit_cast(unsigned, odd ? k0 : r0);
+            pk[3] = __builtin_bit_cast(unsigned, odd ? k1 : r1);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rs_out, st_off + ochan, 0, 0);
         }
+        const unsigned long long te2 = WINO_T();
+        tm_e1 += te1 - tm_mark;
+        tm_e2 += te2 - te1;
         if (p.gn_ws) {
             // per-channel totals by the transpose-reduce of conv_f16s.hip: afterwards the lane with bits (b5 b4 b3 b2 b1 x) holds channel
             // cl = b1 + 2 b2 + 4 b5 + 8 b3 + 16 b4 of this wave's 32; a group of cpg = 2^k consecutive channels is then summed by k more
             // xor-shuffles over the lane bits of cl's low k bits, and one lane per group adds the pair to the fp64 workspace.
-            auto xreduce = [&](float (&v)[16]) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const bool up = (lane & 16) != 0;
-                    const float keep = up ? v[k + 8] : v[k], send = up ? v[k] : v[k + 8];
-                    v[k] = keep + __shfl_xor(send, 16, 64);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bool up = (lane & 8) != 0;
-                    const float keep = up ? v[k + 4] : v[k], send = up ? v[k] : v[k + 4];
-                    v[k] = keep + __shfl_xor(send, 8, 64);
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const bool up = (lane & 4) != 0;
-                    const float keep = up ? v[k + 2] : v[k], send = up ? v[k] : v[k + 2];
-                    v[k] = keep + __shfl_xor(send, 4, 64);
-                }
-                {
-                    const bool up = (lane & 2) != 0;
-                    const float keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
-                    v[0] = keep + __shfl_xor(send, 2, 64);
-                }
-                v[0] += __shfl_xor(v[0], 1, 64);
-            };
-            xreduce(ssum);
-            xreduce(ssq);
+            xreduce16(ssum, lane);      // common.h: DPP + v_permlane16_swap, no LDS traffic
+            xreduce16(ssq, lane);
             float s1 = ssum[0], s2 = ssq[0];
             const int cpg = p.Cout / p.gn_groups;
             const int cl = ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + 4 * half + 8 * ((lane >> 3) & 1) + 16 * ((lane >> 4) & 1);
-            // lane masks of cl's bits 0..4: 2, 4, 32, 8, 16
             int k = 0;
             const bool pow2 = (cpg & (cpg - 1)) == 0;
-#pragma unroll
-            for (int kk = 0; kk < 5; ++kk) {
-                constexpr int bitmask[5] = {2, 4, 32, 8, 16};
-                if (pow2 && (1 << kk) < cpg) {                               // wave-uniform
-                    s1 += __shfl_xor(s1, bitmask[kk], 64);
-                    s2 += __shfl_xor(s2, bitmask[kk], 64);
-                    k = kk + 1;
-                }
-            }
+            // lane masks of cl's bits 0..4: 2, 4, 32, 8, 16 (wave-uniform conditions; the mask-4 level needs the mask-2 level before it: common.h)
+            if (pow2 && cpg > 1) { s1 = xor_sum<2>(s1); s2 = xor_sum<2>(s2); k = 1; }
+            if (pow2 && cpg > 2) { s1 = xor_sum<4>(s1); s2 = xor_sum<4>(s2); k = 2; }
+            if (pow2 && cpg > 4) { s1 = xor_sum<32>(s1); s2 = xor_sum<32>(s2); k = 3; }
+            if (pow2 && cpg > 8) { s1 = xor_sum<8>(s1); s2 = xor_sum<8>(s2); k = 4; }
+            if (pow2 && cpg > 16) { s1 = xor_sum<16>(s1); s2 = xor_sum<16>(s2); k = 5; }
             const int span = pow2 ? (1 << k) : 1;                            // channels whose total this lane now holds
             const int co = mt * 32 + cl;
             if ((lane & 1) == 0 && (cl & (span - 1)) == 0 && co < p.Cout) {
@@ -878,10 +840,12 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
                 atomicAdd(w + 1, (double)s2);
             }
         }
+        tm_e3 += WINO_T() - te2;
     }
     if (N & 1) __syncthreads();                           // the staging waves pad an odd chunk stream to whole pairs
     tm_epi += WINO_T() - tm_mark;
     WINO_ADD(0, tm_wait); WINO_ADD(1, tm_comp); WINO_ADD(2, tm_epi); WINO_ADD(6, 1); WINO_ADD(7, N);
+    WINO_ADD(8, tm_e1); WINO_ADD(9, tm_e2); WINO_ADD(10, tm_e3);
     CF_CLOCK_END(g_clock_wino);
 }
 
@@ -1038,8 +1002,9 @@ static void wino_params(ConvParams& p, const float* x1, int C1, const float* x2,
 
 CF_CLOCK_READER(cf_debug_clock_wino, cf::g_clock_wino)
 #ifdef CF_CLOCK_STAMPS
-extern "C" int cf_debug_wino_phases(unsigned long long* out8) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern "C" int cf_debug_wino_phases(unsigned long long* out12) {
+    unsigned long long* out8 = out12;
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (hipDeviceSynchronize() != hipSuccess) return CF_ERR_LAUNCH;
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(cf::g_wino_phase), sizeof(z)) != hipSuccess) return CF_ERR_LAUNCH;
     if (hipMemcpyToSymbol(HIP_SYMBOL(cf::g_wino_phase), z, sizeof(z)) != hipSuccess) return CF_ERR_LAUNCH;

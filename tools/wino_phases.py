@@ -38,7 +38,7 @@ for (B, C1, C2, H, Cout, pre) in [(128, 128, 0, 128, 128, None), (64, 256, 256, 
     for _ in range(3):
         run()
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 12)()
     fn(buf)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -52,5 +52,7 @@ for (B, C1, C2, H, Cout, pre) in [(128, 128, 0, 128, 128, None), (64, 256, 256, 
     us = e0.elapsed_time(e1) * 100.0
     print("B%d C%d+%d %dx%d -> %d %s%s: %.0f us | per chunk: MFMA wave wait %.0f compute %.0f epilogue+setup %.0f | staging wave write %.0f issue %.0f wait %.0f clocks"
           % (B, C1, C2, H, H, Cout, pre or "plain", " (zeros)" if zeros else "", us, v[0] / ch, v[1] / ch, v[2] / ch, v[3] / ch, v[4] / ch, v[5] / ch), flush=True)
+    items = ch / ((C1 + C2 + 15) // 16)
+    print("    epilogue per item: output transform + activation %.0f | stores + sums %.0f | statistics reduce + atomics %.0f clocks" % (v[8] / items, v[9] / items, v[10] / items), flush=True)
     del x1, x2
     torch.cuda.empty_cache()
