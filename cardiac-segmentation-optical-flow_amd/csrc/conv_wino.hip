@@ -447,6 +447,9 @@ conv_wino_kernel(const ConvParams p, const WinoGeom g, const _Float16* __restric
 // and measured against this one and lost: the epilogue handed to the staging waves through an LDS buffer (their stores sit in the same
 // in-order vmcnt queue as the staged loads), and a 4 + 2 + 2 split with dedicated epilogue waves (two staging waves with two tasks each
 // get ~6 vector-instruction slots per MFMA of their SIMD and fall behind): -8 ... -25 %.
+// Wave priorities (s_setprio 3 on one role, whole kernel or epilogue only): staging waves high = -8 % on plain layers, +<= 1 % with a deferred
+// normalisation; MFMA waves high = no change.  The epilogue (~8 000 clocks per item: output transform 1 500, stores + sums 3 200, statistics
+// 2 200) is ~800 vector instructions on a SIMD shared with a staging wave; dwordx4 instead of dwordx2 stores did not move it.
 // Deferred normalisation: the {mean, scale, shift} quads come straight from global memory with the chunk's loads (no LDS table: items of a
 // band cross samples).
 struct StageRegs {
