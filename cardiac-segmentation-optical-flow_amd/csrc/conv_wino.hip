@@ -11,7 +11,7 @@
 //
 // i.e. 4 x 3 = 12 MFMA k-steps per pair of output columns and 16-channel chunk where the direct form needs 2 x 9 = 18: 1.5x fewer
 // MFMAs for the same result.  ky stays a direct sum, so nothing is exchanged between waves and the output transform needs no LDS.
-// Numerics (tools/winograd_eval.py --row): max |err| / max|y| 3-5e-7 against fp64 at 128 / 256 channels, the same as the direct
+// Numerics (tools/winograd_eval.py --row): max |err| / max|y| 2-8e-7 against fp64 at 128 / 256 channels, the same as the direct
 // 3-term form and as an fp32 convolution.
 //
 // Structure (one workgroup = 4 waves = 128 output channels x NTW x 64 output pixels):
