@@ -206,8 +206,9 @@ int cf_conv2d_f16s_prenorm(const float* x, int C, const float* in_norm, float in
  * a shape qualifies (no launch); the calls fail with CF_ERR_ARG otherwise (the caller stays on cf_conv2d_f16s).  CF_CONV_WINO=0 in the
  * environment makes cf_conv2d_wino_ok answer 0 for every shape (A/B knob). */
 int cf_conv2d_wino_ok(int B, int C1, int C2, int H, int W, int Cout, int prenorm);
-/* route level (tests, A/B runs): 0 = off, 1 = automatic workgroup shape (default), 2 / 4 = force 2 / 4 unit tiles per wave where the geometry
- * allows (initial value from CF_CONV_WINO and CF_WINO_NTW).  Returns the previous level. */
+/* route level (tests, A/B runs): 0 = off, 1 = automatic (default: the persistent wave-specialised kernel where a layer has at least two items per
+ * CU, else one tile per workgroup), 2 / 4 = force the one-tile kernel with 2 / 4 unit tiles per wave, 8 = force the persistent kernel -- each
+ * where the geometry allows (initial value from CF_CONV_WINO).  Returns the previous level. */
 int cf_conv_wino_enable(int level);
 int cf_conv2d_wino(const float* x1, int C1, const float* x2, int C2, const void* wpk, const float* bias, const float* res, float* out,
                    int out_ctotal, int out_coff, int B, int H, int W, int Cout, int act, float alpha, double* gn_ws, int gn_groups,
