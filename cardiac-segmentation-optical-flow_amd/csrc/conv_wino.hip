@@ -55,6 +55,7 @@ struct WinoGeom {
 // Compile-time on purpose: a run-time knob made every load conditional and the compiler's counted waits collapsed to vmcnt(0).
 
 constexpr int W_REC = 80, W_CK = 16, W_NSTEP = 12;
+constexpr int PS_NBUF = 4;        // LDS V buffers of the persistent kernel (one barrier per pair of chunks)
 CF_CLOCK_DECL(g_clock_wino)
 #ifdef CF_CLOCK_STAMPS
 // phase totals of the persistent kernel (shader clocks, lane 0 of MFMA wave 0 and of staging wave 4 of every workgroup):
@@ -436,10 +437,13 @@ conv_wino_kernel(const ConvParams p, const WinoGeom g, const _Float16* __restric
 //   * the MFMA waves issue nothing but weight-fragment loads (three steps ahead), V-record reads (one step ahead) and MFMAs, one barrier
 //     per 16-channel chunk, and run the item's epilogue (output transform, bias, activation, 32 eight-byte stores per lane, statistics by
 //     shuffles + one fp64 atomic pair per group -- no LDS, no barrier);
-//   * the staging waves run the chunk stream ACROSS item boundaries, two chunks of loads in flight (two register sets), one LDS buffer
-//     ahead of the MFMA waves;
-//   * barrier k: "chunk k is in LDS" for the MFMA waves and "chunk k - 1 has been read" for the staging waves (which then overwrite that
-//     buffer with chunk k + 1); both roles execute exactly one barrier per chunk of the stream (an odd stream is padded to whole pairs).
+//   * the staging waves run the chunk stream ACROSS item boundaries, two chunks of loads in flight (two register sets), up to two LDS buffers
+//     ahead of the MFMA waves (four V buffers);
+//   * ONE barrier per PAIR of chunks: barrier j = "chunks 2j, 2j + 1 are in LDS" for the MFMA waves and "chunks 2j - 2, 2j - 1 have been read"
+//     for the staging waves (which then overwrite those buffers with chunks 2j + 2, 2j + 3); both roles execute ceil(N / 2) barriers.  (With a
+//     barrier per chunk and two buffers the MFMA waves waited 500-700 clocks per chunk; with pairs they wait 170-270 -- and compute 300 clocks
+//     longer per chunk, because the staging wave of their SIMD is now busy beside them: the layer times moved by 0 ... +4 %.  The CU, and on data
+//     the board's power limit, are what is shared; the synchronisation was not the cost.)
 // Where its clocks go (make clock + tools/wino_phases.py, profiles/r04_wino_phases.txt), per 16-channel chunk of 72 MFMAs = 2 304 clocks:
 // MFMA wave 3 270 in the chunk loop (2 560 without the weight-fragment loads, make clock ABL=2) + 1 110 of epilogue at 8 chunks per item
 // (the stores are issue-bound: ~8 700 clocks per item) + 300-500 at the barrier; staging wave ~2 800 for ~200 vector instructions beside
@@ -582,7 +586,7 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
 #pragma unroll
             for (int t = 0; t < VT; ++t) {
                 const StageRegs& R = RR[t];
-                unsigned char* base = lds + (gc & 1) * buf_bytes + v_lds[t];
+                unsigned char* base = lds + (gc & (PS_NBUF - 1)) * buf_bytes + v_lds[t];
                 f16x4 hi[2][4], lo[2][4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -627,26 +631,27 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
         issue(B);
         unsigned long long tw = 0, ti = 0, tb = 0;
         (void)tw; (void)ti; (void)tb;
-        // Both halves of the body are UNCONDITIONAL (an odd stream is padded by one chunk: the cursor saturates, the extra chunk lands in the
-        // buffer nobody reads any more, and the other waves execute one matching extra barrier).  With the second half under `if (gc + 1 < N)`
-        // the loop header had a predecessor on which set B had not been re-issued, and the compiler's wait for set A there came out as
-        // vmcnt(0): every other chunk waited for loads issued half an iteration earlier.
+        // Both halves of the body are UNCONDITIONAL (an odd stream is padded by one chunk: the cursor saturates and the extra chunk lands in a
+        // buffer nobody reads any more).  With the second half under `if (gc + 1 < N)` the loop header had a predecessor on which set B had not
+        // been re-issued, and the compiler's wait for set A there came out as vmcnt(0).
+        // ONE barrier per PAIR of chunks, four LDS buffers: barrier j says "chunks 2j, 2j + 1 are in LDS" to the MFMA waves and "chunks 2j - 2,
+        // 2j - 1 have been read" to these waves, which then overwrite those two buffers with chunks 2j + 2, 2j + 3.  With a barrier per chunk and
+        // two buffers the roles ran in lockstep one chunk apart: the MFMA waves paid every chunk's jitter at a barrier (500-700 clocks per
+        // chunk) and these waves could get only one chunk ahead during an item's epilogue (profiles/r04_wino_phases.txt).
         for (int gc = 0; gc < N; gc += 2) {
             unsigned long long t0 = WINO_T();
             write(A, gc);
             unsigned long long t1 = WINO_T();
             issue(A);                                     // chunk gc + 2 (or the stream's last chunk again)
             unsigned long long t2 = WINO_T();
-            __syncthreads();
-            unsigned long long t3 = WINO_T();
-            tw += t1 - t0; ti += t2 - t1; tb += t3 - t2;
+            tw += t1 - t0; ti += t2 - t1;
             t0 = WINO_T();
             write(B, gc + 1);
             t1 = WINO_T();
             issue(B);
             t2 = WINO_T();
             __syncthreads();
-            t3 = WINO_T();
+            const unsigned long long t3 = WINO_T();
             tw += t1 - t0; ti += t2 - t1; tb += t3 - t2;
         }
         WINO_ADD(3, tw); WINO_ADD(4, ti); WINO_ADD(5, tb);
@@ -713,11 +718,11 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
             {
                 const unsigned long long ta = WINO_T();
                 if (c == 0) tm_epi += ta - tm_mark; else tm_comp += ta - tm_mark;
-                __syncthreads();                          // chunk gc is in LDS
+                if ((gc & 1) == 0) __syncthreads();       // chunks gc and gc + 1 are in LDS (one barrier per pair: see the staging loop)
                 tm_mark = WINO_T();
                 tm_wait += tm_mark - ta;
             }
-            const unsigned char* xb = lds + (gc & 1) * buf_bytes;
+            const unsigned char* xb = lds + (gc & (PS_NBUF - 1)) * buf_bytes;
             load_b(xb, 0, 0);
 #pragma unroll
             for (int step = 0; step < NSTEP; ++step) {
@@ -845,7 +850,6 @@ conv_wino_ps_kernel(const ConvParams p, const WinoGeom g, const _Float16* __rest
         }
         tm_e3 += WINO_T() - te2;
     }
-    if (N & 1) __syncthreads();                           // the staging waves pad an odd chunk stream to whole pairs
     tm_epi += WINO_T() - tm_mark;
     WINO_ADD(0, tm_wait); WINO_ADD(1, tm_comp); WINO_ADD(2, tm_epi); WINO_ADD(6, 1); WINO_ADD(7, N);
     WINO_ADD(8, tm_e1); WINO_ADD(9, tm_e2); WINO_ADD(10, tm_e3);
@@ -890,6 +894,7 @@ bool wino_geometry(const ConvParams& p, int ntw, WinoGeom& g) {
 }
 
 size_t wino_lds_bytes(const WinoGeom& g, bool pre) { return (size_t)2 * g.PH * g.ROWP + (pre ? (size_t)3 * g.nchunk * W_CK * sizeof(float) : 0); }
+size_t wino_ps_lds_bytes(const WinoGeom& g) { return (size_t)PS_NBUF * g.PH * g.ROWP; }
 
 template <int NTW, int PRE>
 int launch_wino(const ConvParams& p, const WinoGeom& g, const _Float16* wpk, hipStream_t s) {
@@ -917,7 +922,8 @@ int launch_wino(const ConvParams& p, const WinoGeom& g, const _Float16* wpk, hip
 
 template <int PRE>
 int launch_wino_ps(const ConvParams& p, const WinoGeom& g, const _Float16* wpk, hipStream_t s) {
-    const size_t lds_bytes = (size_t)2 * g.PH * g.ROWP;
+    const size_t lds_bytes = wino_ps_lds_bytes(g);
+    if (lds_bytes > 160 * 1024) { set_error("conv_wino (persistent): LDS buffers too large"); return CF_ERR_ARG; }
     auto kern = conv_wino_ps_kernel<PRE>;
     static bool attr_set[64] = {};
     const int dev = current_device_slot();
@@ -944,7 +950,7 @@ int launch_wino_ps(const ConvParams& p, const WinoGeom& g, const _Float16* wpk, 
 int wino_pick_ntw(const ConvParams& p, WinoGeom& g) {
     const int lvl = wino_level();
     const long cblocks = (p.Cout + 127) / 128;
-    if ((lvl == 1 || lvl == 8) && wino_geometry(p, 2, g) && g.ntask <= 256 && (long)2 * g.PH * g.ROWP <= 160 * 1024 &&
+    if ((lvl == 1 || lvl == 8) && wino_geometry(p, 2, g) && g.ntask <= 256 && wino_ps_lds_bytes(g) <= 160 * 1024 &&
         (!p.in_norm || ((p.C1 & 3) == 0 && (reinterpret_cast<uintptr_t>(p.in_norm) & 15) == 0))) {
         const long nitems = (long)g.tiles_x * g.tiles_y * p.B * cblocks;
         if (lvl == 8 || nitems >= 2L * wino_num_cus()) return 8;
