@@ -105,6 +105,14 @@ time.sleep(2.0)
 idle = [s[1] for s in samples if s[1] == s[1]]
 print("idle: %.0f W" % (sum(idle) / max(len(idle), 1)))
 only_corr = len(sys.argv) > 1 and sys.argv[1] == "corr"
+if len(sys.argv) > 1 and sys.argv[1] == "wino":
+    # the two Winograd cases only (energy ablations: CINEFLOW_LIB = a clock build made with ABL=n, wrong results by design)
+    f, w_ = wino_case(128, 128, 0, 128, 128)
+    run("wino 128 -> 128, 128x128, B128 (random)", f, w_, "TF")
+    f, w_ = wino_case(64, 256, 256, 64, 256)
+    run("wino 256+256 -> 256, 64x64, B64 (random)", f, w_, "TF")
+    stop = True
+    sys.exit(0)
 f, w_ = conv_case(128, 128, 128, 128)
 run("conv 128 -> 128, 128x128, B128 (random)", f, w_, "TF", secs=1.5 if only_corr else 4.0)
 if not only_corr:
