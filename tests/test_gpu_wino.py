@@ -128,6 +128,53 @@ def test_conv2d_wino_prenorm(dev, wino_level, B, C, H, W, Cout, ntw):
     assert maxdiff(ops.conv2d_wino_prenorm(xd, coefg, -1.0, wpk, wsc, b.to(dev), Cout), wantg) <= 3e-5 * max(float(wantg.abs().max()), 1.0)
 
 
+@pytest.mark.parametrize("B,C1,C2,H,W,Cout,pre", [
+    (72, 144, 0, 32, 32, 128, False),      # 576 items on 256 workgroups: 2-3 items each, 9 chunks per item -> odd AND even chunk streams
+    (40, 64, 48, 32, 64, 256, False),      # two inputs, two 128-channel blocks: 1280 items, 7 chunks per item, bands cross samples and blocks
+    (72, 128, 0, 32, 32, 128, True),       # deferred GroupNorm + GELU: the coefficient quads follow the stream across samples
+    (48, 256, 0, 16, 16, 256, True),       # 16-wide maps (8 units per row), 16 chunks
+])
+def test_conv2d_wino_persistent_stream_across_items(dev, wino_level, B, C1, C2, H, W, Cout, pre):
+    """The persistent kernel at launch sizes where a workgroup walks SEVERAL items: its staging waves run the chunk stream across item (and
+    sample) boundaries two chunks of loads ahead, with one barrier per pair of chunks over four LDS buffers -- odd streams, items of different
+    samples in one stream and the padded last pair are only reached when n_items > n_CUs.  Reference: the direct kernel on the same operands
+    (1e-5: same products, different summation order) and an fp64 convolution on the first and last two samples (2e-5)."""
+    from cineflow import ops
+    wino_level(8)
+    assert ops.wino_ok(B, C1, C2, H, W, Cout, prenorm=pre)
+    x1 = randn(B, C1, H, W, seed=200) * 1.3 + 0.2
+    x2 = randn(B, C2, H, W, seed=201) if C2 else None
+    w = randn(Cout, C1 + C2, 3, 3, seed=202) / math.sqrt((C1 + C2) * 9)
+    b = randn(Cout, seed=203)
+    x1d, x2d = x1.to(dev), None if x2 is None else x2.to(dev)
+    wpk, ws = ops.pack_conv_weight_wino(w.to(dev), c1=C1 if C2 else None)
+    wpd, wsd = ops.pack_conv_weight_f16s(w.to(dev), c1=C1 if C2 else None)
+    if pre:
+        g, bt = randn(C1, seed=204), randn(C1, seed=205)
+        xs = x1.double().view(B, 8, -1)
+        wsum = torch.stack([xs.sum(-1), (xs ** 2).sum(-1)], -1).reshape(-1).to(dev)
+        coef = ops.group_norm_coef(wsum, g.to(dev), bt.to(dev), 8, B, C1, H * W)
+        got, st = ops.conv2d_wino_prenorm(x1d, coef, -1.0, wpk, ws, b.to(dev), Cout, stats_groups=8)
+        wino_level(0)
+        direct = ops.conv2d_f16s_prenorm(x1d, coef, -1.0, wpd, wsd, b.to(dev), Cout) if ops.prenorm_ok(x1d, Cout) else None
+        sel = [0, 1, B - 2, B - 1]
+        xin = F.gelu(F.group_norm(x1[sel].double(), 8, g.double(), bt.double(), eps=1e-5))
+    else:
+        got, st = ops.conv2d_wino(x1d, wpk, ws, b.to(dev), Cout, x2=x2d, stats_groups=8)
+        wino_level(0)
+        direct = ops.conv2d_f16s(x1d, wpd, wsd, b.to(dev), Cout, 3, 3, 1, (1, 1), x2=x2d)
+        sel = [0, 1, B - 2, B - 1]
+        xin = x1[sel].double() if x2 is None else torch.cat([x1[sel], x2[sel]], 1).double()
+    want = F.conv2d(xin, w.double(), b.double(), padding=1)
+    scale = max(float(want.abs().max()), 1.0)
+    assert maxdiff(got[sel], want) <= 2e-5 * scale
+    if direct is not None:
+        assert maxdiff(got, direct.cpu()) <= 1e-5 * scale
+    yo = got.cpu().double().view(B, 8, -1)
+    wst = torch.stack([yo.sum(-1), (yo ** 2).sum(-1)], -1)
+    assert float(((st.cpu().view(B, 8, 2) - wst).abs() / (yo.abs().sum(-1)[..., None] + 1.0)).max()) <= 2e-6, "fused statistics"
+
+
 def test_conv2d_wino_capability_and_errors(dev, wino_level):
     from cineflow import ops
     from cineflow._lib import CineflowError
