@@ -191,7 +191,8 @@ def test_corr_volume_radius4(dev, C, H, W, stride):
 
 
 @pytest.mark.parametrize("B,C,H,W,stride", [(2, 64, 256, 256, 4), (3, 128, 128, 128, 2), (2, 256, 64, 64, 1),      # the three levels of the flow network
-                                            (5, 16, 64, 128, 4), (3, 32, 48, 192, 2), (9, 16, 24, 64, 1)])            # ragged tile counts, bands with < 1 tile
+                                            (5, 16, 64, 128, 4), (3, 32, 48, 192, 2), (9, 16, 24, 64, 1),             # ragged tile counts, bands with < 1 tile
+                                            (9, 64, 256, 256, 4), (20, 128, 128, 128, 2), (70, 256, 64, 64, 1)])      # 4-5 tiles per workgroup: the chunk stream runs across tile (and sample) boundaries
 def test_corr_volume_mfma_vs_oracle_and_vector_kernel(dev, B, C, H, W, stride):
     """the f16-MFMA CorrVolume kernel (csrc/corr_mfma.hip: 2-D banded products of hi/lo-split operands, four split terms inside
     one K = 32 instruction, fp32 accumulation) at the network's three levels with B >= 2, against the oracle at 1e-5 and against the fp32
