@@ -281,6 +281,11 @@ def test_convex_upsample(dev):
     check(ops.convex_upsample(flow.to(dev), mask.to(dev)), OO.convex_upsample(flow, mask), 1e-5)
     seg = randn(1, 4, 8, 8, seed=22)
     check(ops.convex_upsample(seg.to(dev), mask[:1, :, :, :8].contiguous().to(dev)), OO.convex_upsample(seg, mask[:1, :, :, :8]), 1e-5)
+    # the RAFT map size of the bench (32 x 32 -> 256 x 256; the row kernel: one workgroup per map row) and a 40-wide map (a second, partly
+    # filled 32-column block per row); C = 2 takes the row kernel, C = 4 above the flat one
+    for (B, h, w, seed) in ((3, 32, 32, 23), (2, 6, 40, 25)):
+        flow, mask = randn(B, 2, h, w, seed=seed), 2 * randn(B, 576, h, w, seed=seed + 1)
+        check(ops.convex_upsample(flow.to(dev), mask.to(dev)), OO.convex_upsample(flow, mask), 1e-5, "convex upsample %dx%d" % (h, w))
 
 
 # ------------------------------------------------------------------------------------------------ conv
