@@ -184,12 +184,13 @@ constexpr int DPP_ROR8 = 0x128;                       // row_ror:8 = lane ^ 8 in
 constexpr int DPP_HALF_MIRROR = 0x141;                // lane ^ 7 inside each 8 lanes
 // Inline assembly: this hipcc's __builtin_amdgcn_permlane16_swap / 32_swap lose their second result (both members of the returned pair are the
 // new vdst: tools/ubench/xreduce_check.hip).  The s_nop pairs stand in for the hazard recogniser, which does not see inside an asm statement
-// (a VALU write of an operand needs two wait states before the swap reads it, and so does a VALU read after it).
+// (a VALU write of an operand needs wait states before the swap reads it, and so does a VALU read after it: four each way here, twice what
+// the compiler inserts around its own builtin).
 __device__ __forceinline__ void swap_rows16(float& a, float& b) {
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm("s_nop 3\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
 }
 __device__ __forceinline__ void swap_halves32(float& a, float& b) {
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm("s_nop 3\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 3" : "+v"(a), "+v"(b));
 }
 // Transpose-reduce of sixteen per-lane partial sums over the 32 lanes of a wave half: afterwards v[0] of the lane with bits (b4 b3 b2 b1 x)
 // holds register 8 b4 + 4 b3 + 2 b2 + b1 summed over those 32 lanes (both lanes of a pair hold the same).  The level that pairs on lane bit 2
