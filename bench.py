@@ -425,7 +425,7 @@ def bench_raft(args, dev, h, world, rank, steps, warmup):
         "roofline": roofline,
         "roofline_allpairs": hbm_roofline("allpairs_pyramid_kernel (f16-split MFMA product, the 4 pyramid levels from one set of accumulators); 7.67 MB / pair", allp),
         "roofline_lookup": hbm_roofline("corr_lookup_tiled_kernel (324 channels written once per iteration; gathers are cache traffic)", look),
-        "roofline_upsample": hbm_roofline("convex_upsample_kernel (576-channel mask read once per iteration)", up),
+        "roofline_upsample": hbm_roofline("convex_upsample_rows_kernel (576-channel mask read once per iteration, eight adjacent outputs per thread)", up),
     }
 
 
